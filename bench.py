@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s and frame time of the render hot path on MI355X.
+
+A step = one frame of BASELINE.json's headline configuration (configs[1]: 1920x1080, 8 spheres +
+1 plane, 3 lights, depth 3, no AA; synthetic scene = the reference's default scene + 2 spheres).
+With N > 1 ranks (one process per GPU, launched by torch.distributed.run) the SAME frame is cut into
+N column slabs, each rank renders its slab, and the uint8 frame is assembled on rank 0 by an RCCL
+gather — total work is fixed, so `scaling` is "strong".
+
+Inputs (scene, camera) are resident on the device before the timed region; outputs stay in HBM.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(wl, rays_per_frame, min_wall_s=2.5):
+    """The CPU oracle (a C restatement of the reference, kind="port") timed on this box's host cores
+    on whole frames of the same workload, until at least `min_wall_s` of wall time has been spent."""
+    from oracle import oracle as orc
+    orc.build()
+    cam = wl["camera"]
+    threads = orc.max_threads()
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        orc.render(wl["w"], wl["h"], cam.position, cam.rotation, wl["spheres"], wl["lights"], wl["planes"],
+                   wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], raygen=cam.raygen(), want=("u8",),
+                   nthreads=threads)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_wall_s:
+            break
+    return {"value": round(rays_per_frame * frames / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} full {wl['w']}x{wl['h']} frame(s) of the same workload, {dt:.2f} s wall, "
+                      f"{dt * threads:.1f} core-seconds, OpenMP over columns",
+            "frame_ms": round(dt / frames * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=None, help="one of python_ray_tracer_amd.workloads.CONFIGS")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+        a.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import python_ray_tracer_amd as pkg
+    from python_ray_tracer_amd import workloads
+    from python_ray_tracer_amd.distributed import slab_bounds, gather_frame
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    name = a.workload or workloads.HEADLINE
+    wl = workloads.build(name)
+    w, h, cam = wl["w"], wl["h"], wl["camera"]
+    r = pkg.Renderer(local_rank)
+    r.set_scene(wl["spheres"], wl["lights"], wl["planes"])
+    r.set_camera(cam.position, cam.rotation)
+    r.set_raygen(w, h, *cam.raygen())
+    params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"])
+    x0, x1 = slab_bounds(w, world, rank)
+    ws = x1 - x0
+    slab_u8 = torch.zeros((3, ws, h), dtype=torch.uint8, device=dev)
+    slab_f32 = torch.zeros((3, ws, h), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream,
+    frame = None                                       # so the event pairs below bracket exactly the kernel
+
+    def step(ev=None):
+        nonlocal frame
+        if ev:
+            ev[0].record()
+        r.render_device(params, x0, x1, slab_u8.data_ptr(), slab_f32.data_ptr(), ws * h, stream)
+        if ev:
+            ev[1].record()
+        if world > 1:
+            frame = gather_frame(slab_u8, w, h, dist, dst=0)
+        else:
+            frame = slab_u8
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(events[i])
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(a.steps, 1)
+
+    t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, kernel_ms_max = float(t[0]), float(t[1])
+
+    if rank == 0:
+        rays = wl["rays"]
+        if rays is None:   # ray counts of non-headline configs come from the oracle's counters
+            from oracle import oracle as orc
+            c = orc.render(w, h, cam.position, cam.rotation, wl["spheres"], wl["lights"], wl["planes"], wl["amb"], wl["lamb"],
+                           wl["refl"], wl["depth"], wl["aa"], raygen=cam.raygen(), want=())["counters"]
+            rays = dict(closest=c["closest"], shadow=c["shadow"])
+        rays_per_frame = rays["closest"] + rays["shadow"]
+        ms_per_step = dt / a.steps * 1e3
+        # algorithmic HBM bytes of one launch of this rank's kernel: float32 RGB planes (12 B/px) + uint8
+        # frame (3 B/px) stored once, scene + camera read once (DESIGN.md "Measurement")
+        S, L, P = wl["spheres"].shape[1], wl["lights"].shape[1], wl["planes"].shape[1]
+        alg_bytes = ws * h * 15 + 4 * (7 * S + 3 * L + 9 * P) + 96
+        achieved = alg_bytes / (kernel_ms_max * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
+        if world == 1 and name == workloads.HEADLINE and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        frame_host = frame.cpu().numpy()
+        check = None
+        gpath = os.path.join(REPO, "tests", "golden", "frame_c2_1080p.npz")
+        if name == workloads.HEADLINE and os.path.exists(gpath):
+            check = hashlib.sha256(frame_host.tobytes()).hexdigest() == str(np.load(gpath)["sha256_u8"])
+        out = {
+            "metric": "Mrays/sec + frame time (ms) at 1920x1080, 8 spheres, depth=3",
+            "value": round(rays_per_frame / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": name, "width": w, "height": h, "spheres": S, "planes": P, "lights": L,
+                       "depth": wl["depth"], "aa": bool(wl["aa"]), "rays_per_frame": rays_per_frame,
+                       "primary_rays_per_frame": w * h, "outputs": "uint8 (3,w,h) frame + float32 (3,w,h) pre-clip RGB",
+                       "parallelism": f"column slabs x{world}" + (", RCCL gather of the uint8 frame to rank 0" if world > 1 else "")},
+            "frame_ms": round(ms_per_step, 5),
+            "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
+            "frame_matches_reference_sha256": check,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "rt::render_kernel", "kernel_ms": round(kernel_ms_max, 5), "algorithmic_bytes": alg_bytes,
+                         "note": "float64 VALU-bound by construction (about 15 B and ~2 kflop per pixel): the HBM fraction "
+                                 "is reported because BASELINE.json's north_star asks for it, not because HBM limits this kernel"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, rays_per_frame)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * mi355rt.h — C ABI of libmi355rt.so, the MI355X (gfx950) replacement for the per-pixel
+ * ray-trace path of peter-seres/python-ray-tracer.
+ *
+ * The boundary being replaced is the numba kernel launch (reference paths are relative to
+ * /root/reference/src):
+ *
+ *     render[blockspergrid, threadsperblock](pixel_loc, result, camera_origin, camera_rotation,
+ *                                            spheres, lights, planes, amb, lamb, refl,
+ *                                            refl_depth, aliasing)          main.py:41-42
+ *     signature                                                             ray_tracing/kernels.py:7
+ *     exported name  `from ray_tracing import render`                       ray_tracing/__init__.py:1
+ *
+ * plus the data movement around it: `cuda.to_device(...)` x7 (main.py:19-32) and
+ * `result.copy_to_host()` (main.py:51).  Each entry point below names the piece of that call it
+ * stands for.  Plain pointers and sizes only; no C++ or torch types cross this boundary; no
+ * exception crosses it (every function returns an rt_status).
+ *
+ * Threading: a context is not thread-safe; use one context per host thread / per GPU.
+ * The library has no CPU fallback: without a usable HIP device rt_create fails.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+#define RT_MAX_DEPTH 16      /* entries of rt_params.refl_pow (reflection bounces) */
+#define RT_MAX_SPHERES 1024  /* scene limits: the packed scene must fit one workgroup's LDS */
+#define RT_MAX_PLANES 64
+#define RT_MAX_LIGHTS 64
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_BAD_ARG = -1,   /* NULL pointer, size out of range, x-range outside the frame ... */
+    RT_ERR_HIP = -2,       /* a HIP runtime call failed; see rt_last_error */
+    RT_ERR_NO_DEVICE = -3, /* no HIP device / device index out of range */
+    RT_ERR_STATE = -4,     /* render called before scene / camera / ray grid were set */
+    RT_ERR_ALLOC = -5      /* host or device allocation failed */
+} rt_status;
+
+/* aa_mode */
+#define RT_AA_NONE 0      /* aliasing=False                                        kernels.py:26 only */
+#define RT_AA_REFERENCE 1 /* aliasing=True: the reference's 3x3 half-pixel taps incl. its G/B
+                             accumulation order (kernels.py:29-65) on 1<=x<=w-2, 1<=y<=h-2; the
+                             frame border, where the reference indexes out of bounds, gets one tap */
+
+/* flags */
+#define RT_FLAG_TYPED_BIAS 1 /* evaluate BIAS*N of a plane hit (trace.py:82-83) in float64 (numba
+                                typing) instead of float32 (NumPy>=2 simulator promotion; default,
+                                the variant pinned by the golden vectors) */
+#define RT_FLAG_U8_RGB 2     /* store the uint8 frame as (R,G,B); default is the reference's
+                                (R,B,G) order (common.py:60-63) */
+
+typedef struct rt_ctx rt_ctx;
+
+/* Shader scalars of the launch (main.py:11, kernels.py:7 args amb, lamb, refl, refl_depth, aliasing).
+ * refl_pow[i] must hold refl ** (i+1) as the host language evaluates it (trace.py:131). */
+typedef struct rt_params {
+    double amb;
+    double lamb;
+    double refl_pow[RT_MAX_DEPTH];
+    int32_t depth;   /* refl_depth, 0..RT_MAX_DEPTH */
+    int32_t aa_mode; /* RT_AA_* */
+    int32_t flags;   /* RT_FLAG_* */
+    int32_t reserved;
+} rt_params;
+
+/* Static facts about the compiled kernel (for reports). */
+typedef struct rt_kernel_info {
+    int32_t vgprs;          /* numRegs of the render kernel */
+    int32_t sgprs;
+    int32_t lds_static;     /* bytes */
+    int32_t max_threads;    /* per workgroup */
+    int32_t wave_size;
+    int32_t cu_count;
+    int32_t clock_khz;
+    int32_t reserved;
+} rt_kernel_info;
+
+int rt_abi_version(void);
+
+/* Number of HIP devices visible to this process. */
+int rt_device_count(int *count);
+
+/* Create / destroy a context bound to one GPU (owns a stream, scene/camera buffers, timing events).
+ * Replaces numba's implicit CUDA context creation at first `cuda.to_device` (main.py:19). */
+int rt_create(rt_ctx **ctx, int device);
+int rt_destroy(rt_ctx *ctx);
+
+/* Message for the last error on this context (or, with ctx == NULL, for a failed rt_create). */
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Scene arrays exactly as Scene.generate_scene() returns them (scene/scene.py:69-97):
+ *   spheres float32 (7,S) C-order, rows cx,cy,cz,r,R,G,B     replaces cuda.to_device(spheres_host) main.py:19
+ *   lights  float32 (3,L) rows x,y,z                          replaces cuda.to_device(light_host)   main.py:20
+ *   planes  float32 (9,P) rows ox,oy,oz,nx,ny,nz,R,G,B        replaces cuda.to_device(planes_host)  main.py:21
+ * Any of S, L, P may be 0 (the pointer is then ignored). */
+int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, int L,
+                 const float *planes, int P, int flags);
+
+/* camera_origin float64 (3,) and camera_rotation float64 (3,3) C-order   main.py:27-28 */
+int rt_set_camera(rt_ctx *ctx, const double origin[3], const double rotation[9]);
+
+/* The pixel grid of Camera.generate_pixel_locations() (scene/camera.py:18-26) in closed form:
+ *   pixel_loc[:, x, y] = (px, x*dy + y0, y*dz + z0)      (one multiply, one add, as np.mgrid does)
+ * The kernel generates primary rays from this; no (3,w,h) array is read.   replaces main.py:29 */
+int rt_set_raygen(rt_ctx *ctx, int w, int h, double px, double y0, double dy, double z0, double dz);
+
+/* Drop-in alternative: an explicit float64 (3,w,h) C-order pixel_loc array (host pointer), uploaded
+ * and read by the kernel as kernels.py:19 does.                          replaces main.py:29 */
+int rt_set_pixel_loc(rt_ctx *ctx, const double *pixel_loc, int w, int h);
+
+/* One launch of the render path for frame columns x0 <= x < x1 (x1 - x0 need not be a multiple of
+ * the tile size), into HOST buffers; synchronous (includes the D2H copy — main.py:41-42 + :51).
+ *   out_u8  : uint8   (3, x1-x0, h) C-order, index [c, x-x0, y]; channel order per flags; or NULL
+ *   out_f32 : float32 (3, x1-x0, h) the (R,G,B) handed to clip_color_vector (kernels.py:69),
+ *             true channel order, unclamped; or NULL */
+int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32);
+
+/* The same launch into DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = the
+ * context's own stream).  Element [c, x, y] (x0 <= x < x1) is stored at
+ *   base[c * plane_stride + (x - x0) * h + y]
+ * so plane_stride = (x1-x0)*h gives a compact slab and, with base pointing at column x0 of a full
+ * frame, plane_stride = w*h renders the slab in place.  Either pointer may be NULL. */
+int rt_render_device(rt_ctx *ctx, const rt_params *params, int x0, int x1, void *d_u8, void *d_f32,
+                     int64_t plane_stride, void *stream);
+
+/* Device memory owned by the caller (the DeviceNDArray that `cuda.to_device(np.zeros((3,w,h)))`
+ * returns, main.py:32, and `result.copy_to_host()`, main.py:51).  The copies are ordered on the
+ * context's stream and return when the bytes have arrived. */
+int rt_malloc(rt_ctx *ctx, size_t bytes, void **dptr);
+int rt_free(rt_ctx *ctx, void *dptr);
+int rt_memcpy_h2d(rt_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int rt_memcpy_d2h(rt_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* Block until everything queued on the context's stream is done (the implicit sync of
+ * copy_to_host, main.py:51). */
+int rt_sync(rt_ctx *ctx);
+
+/* hipEvent pair on `stream` (NULL = context stream) around whatever is launched in between;
+ * rt_timer_end synchronises on the second event and returns elapsed milliseconds. */
+int rt_timer_begin(rt_ctx *ctx, void *stream);
+int rt_timer_end(rt_ctx *ctx, void *stream, float *ms);
+
+int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RT_H */

@@ -1,0 +1,68 @@
+"""ctypes binding of libmi355rt.so — one prototype per declaration in include/mi355rt.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libmi355rt.so")
+
+RT_ABI_VERSION = 1
+RT_MAX_DEPTH = 16
+RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
+RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
+RT_AA_NONE, RT_AA_REFERENCE = 0, 1
+RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB = 1, 2
+
+STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_DEVICE", -4: "RT_ERR_STATE", -5: "RT_ERR_ALLOC"}
+
+
+class rt_params(C.Structure):
+    _fields_ = [("amb", C.c_double), ("lamb", C.c_double), ("refl_pow", C.c_double * RT_MAX_DEPTH),
+                ("depth", C.c_int32), ("aa_mode", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class rt_kernel_info(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vgprs", "sgprs", "lds_static", "max_threads", "wave_size", "cu_count", "clock_khz", "reserved")]
+
+
+# name -> (restype, argtypes); must list every function include/mi355rt.h declares.
+_dp, _fp, _vp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_void_p
+PROTOTYPES = {
+    "rt_abi_version": (C.c_int, []),
+    "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rt_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "rt_destroy": (C.c_int, [_vp]),
+    "rt_last_error": (C.c_char_p, [_vp]),
+    "rt_set_scene": (C.c_int, [_vp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int]),
+    "rt_set_camera": (C.c_int, [_vp, _dp, _dp]),
+    "rt_set_raygen": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "rt_set_pixel_loc": (C.c_int, [_vp, _dp, C.c_int, C.c_int]),
+    "rt_render": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp]),
+    "rt_render_device": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
+    "rt_sync": (C.c_int, [_vp]),
+    "rt_timer_begin": (C.c_int, [_vp, _vp]),
+    "rt_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "rt_get_kernel_info": (C.c_int, [_vp, C.POINTER(rt_kernel_info)]),
+    "rt_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rt_free": (C.c_int, [_vp, _vp]),
+    "rt_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "rt_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmi355rt.so.  No fallback: a missing or stale library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"(or `make -C python-ray-tracer_amd/csrc`); there is no CPU fallback")
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if lib.rt_abi_version() != RT_ABI_VERSION:
+            raise ImportError(f"{SO_PATH}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib

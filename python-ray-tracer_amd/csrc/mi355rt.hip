@@ -1,0 +1,373 @@
+// mi355rt.hip — host side of libmi355rt.so: the C ABI of include/mi355rt.h over the gfx950
+// render kernel in rt_device.h.  HIP only (no torch, no CPU fallback): without a HIP device
+// rt_create fails and nothing renders.
+#include "../../include/mi355rt.h"
+#include "rt_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+std::string g_create_error;
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Buf scene, pixel_loc, u8, f32;
+    int S = 0, P = 0, L = 0;
+    bool have_scene = false, have_cam = false, have_grid = false, explicit_grid = false;
+    double cam_o[3] = {0, 0, 0}, cam_R[9] = {0};
+    int w = 0, h = 0;
+    double px = 0, y0 = 0, dy = 0, z0 = 0, dz = 0;
+    size_t lds_limit_set = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(rt_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((ctx), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+int ensure(rt_ctx *ctx, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return RT_OK;
+    if (b.p) { RT_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    RT_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return RT_OK;
+}
+
+// common.py:104-110 on float32 inputs (float32 squares/sum, sqrt of that sum rounded to float32,
+// float32 divisions) — the shading normal of a plane, hoisted to scene-upload time.
+void plane_normal_f32(const float n[3], float out[3])
+{
+    const float s = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const float norm = (float)std::sqrt((double)s);
+    out[0] = n[0] / norm; out[1] = n[1] / norm; out[2] = n[2] / norm;
+}
+
+int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
+{
+    if (!p) return fail(ctx, RT_ERR_BAD_ARG, "params is NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "rt_set_scene has not been called");
+    if (!ctx->have_cam) return fail(ctx, RT_ERR_STATE, "rt_set_camera has not been called");
+    if (!ctx->have_grid) return fail(ctx, RT_ERR_STATE, "rt_set_raygen / rt_set_pixel_loc has not been called");
+    if (p->depth < 0 || p->depth > RT_MAX_DEPTH) return fail(ctx, RT_ERR_BAD_ARG, "depth outside 0..RT_MAX_DEPTH");
+    if (p->aa_mode != RT_AA_NONE && p->aa_mode != RT_AA_REFERENCE) return fail(ctx, RT_ERR_BAD_ARG, "unknown aa_mode");
+    if (x0 < 0 || x1 > ctx->w || x0 >= x1) return fail(ctx, RT_ERR_BAD_ARG, "column range must satisfy 0 <= x0 < x1 <= w");
+    return RT_OK;
+}
+
+int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_f32, int64_t plane_stride,
+           hipStream_t stream)
+{
+    rt::KParams k;
+    std::memset(&k, 0, sizeof k);
+    k.scene = (const double *)ctx->scene.p;
+    k.pixel_loc = ctx->explicit_grid ? (const double *)ctx->pixel_loc.p : nullptr;
+    k.out_u8 = (uint8_t *)d_u8;
+    k.out_f32 = (float *)d_f32;
+    k.plane_stride = plane_stride;
+    k.w = ctx->w; k.h = ctx->h; k.x0 = x0; k.x1 = x1;
+    k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth;
+    k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0;
+    k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
+    const int tiles_x = (x1 - x0 + rt::TILE - 1) / rt::TILE;
+    k.ntiles = tiles_x * k.tiles_y;
+    k.px = ctx->px; k.y0 = ctx->y0; k.dy = ctx->dy; k.z0 = ctx->z0; k.dz = ctx->dz;
+    std::memcpy(k.cam_o, ctx->cam_o, sizeof k.cam_o);
+    std::memcpy(k.cam_R, ctx->cam_R, sizeof k.cam_R);
+    k.amb = p->amb; k.lamb = p->lamb;
+    std::memcpy(k.refl_pow, p->refl_pow, sizeof k.refl_pow);
+
+    const size_t lds = sizeof(double) * ((size_t)ctx->S * rt::SPH_STRIDE + (size_t)ctx->P * rt::PL_STRIDE + (size_t)ctx->L * rt::LT_STRIDE);
+    if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
+        RT_HIP(ctx, hipFuncSetAttribute((const void *)rt::render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->lds_limit_set = lds;
+    }
+    const unsigned grid = (unsigned)((k.ntiles + rt::WAVES_PER_WG - 1) / rt::WAVES_PER_WG);
+    hipLaunchKernelGGL(rt::render_kernel, dim3(grid), dim3(rt::WG_THREADS), lds, stream, k);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(int *count)
+{
+    if (!count) return RT_ERR_BAD_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return RT_ERR_NO_DEVICE; }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_create(rt_ctx **out, int device)
+{
+    if (!out) return fail(nullptr, RT_ERR_BAD_ARG, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= n) return fail(nullptr, RT_ERR_NO_DEVICE, "device index out of range");
+    rt_ctx *ctx = new (std::nothrow) rt_ctx;
+    if (!ctx) return fail(nullptr, RT_ERR_ALLOC, "out of host memory");
+    ctx->device = device;
+    hipError_t s;
+    if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        std::string m = std::string("context setup: ") + hipGetErrorString(s);
+        delete ctx;
+        return fail(nullptr, RT_ERR_HIP, m);
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32})
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, int L, const float *planes, int P, int flags)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (S < 0 || S > RT_MAX_SPHERES || L < 0 || L > RT_MAX_LIGHTS || P < 0 || P > RT_MAX_PLANES)
+        return fail(ctx, RT_ERR_BAD_ARG, "scene size outside RT_MAX_SPHERES / RT_MAX_LIGHTS / RT_MAX_PLANES");
+    if ((S && !spheres) || (L && !lights) || (P && !planes)) return fail(ctx, RT_ERR_BAD_ARG, "NULL scene array with non-zero count");
+    try {
+        // Packed float64 records (layout: rt_device.h).  All float32 sub-expressions of the reference
+        // are evaluated here, once, in float32: r*r (intersections.py:21), the plane shading normal
+        // (common.py:104-110) and BIAS*N of a plane hit (trace.py:82-83).
+        std::vector<double> rec((size_t)S * rt::SPH_STRIDE + (size_t)P * rt::PL_STRIDE + (size_t)L * rt::LT_STRIDE + 1, 0.0);
+        double *sp = rec.data();
+        for (int k = 0; k < S; ++k, sp += rt::SPH_STRIDE) {
+            const float r = spheres[3 * S + k];
+            const float r2 = r * r;
+            sp[0] = spheres[0 * S + k]; sp[1] = spheres[1 * S + k]; sp[2] = spheres[2 * S + k]; sp[3] = (double)r2;
+            sp[4] = spheres[4 * S + k]; sp[5] = spheres[5 * S + k]; sp[6] = spheres[6 * S + k];
+        }
+        for (int k = 0; k < P; ++k, sp += rt::PL_STRIDE) {
+            for (int i = 0; i < 6; ++i) sp[i] = planes[i * P + k];
+            const float nraw[3] = {planes[3 * P + k], planes[4 * P + k], planes[5 * P + k]};
+            float nf[3];
+            plane_normal_f32(nraw, nf);
+            const double BIAS = 0.0002;
+            const float bf = (float)BIAS;
+            for (int i = 0; i < 3; ++i) {
+                sp[6 + i] = (double)nf[i];
+                sp[9 + i] = (flags & RT_FLAG_TYPED_BIAS) ? BIAS * (double)nf[i] : (double)(bf * nf[i]);
+                sp[12 + i] = planes[(6 + i) * P + k];
+            }
+        }
+        for (int k = 0; k < L; ++k, sp += rt::LT_STRIDE) {
+            sp[0] = lights[0 * L + k]; sp[1] = lights[1 * L + k]; sp[2] = lights[2 * L + k];
+        }
+        RT_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t bytes = rec.size() * sizeof(double);
+        int rc = ensure(ctx, ctx->scene, bytes);
+        if (rc != RT_OK) return rc;
+        RT_HIP(ctx, hipMemcpyAsync(ctx->scene.p, rec.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // rec is about to go out of scope
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RT_ERR_ALLOC, "out of host memory");
+    }
+    ctx->S = S; ctx->P = P; ctx->L = L;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx *ctx, const double origin[3], const double rotation[9])
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!origin || !rotation) return fail(ctx, RT_ERR_BAD_ARG, "NULL camera array");
+    std::memcpy(ctx->cam_o, origin, sizeof ctx->cam_o);
+    std::memcpy(ctx->cam_R, rotation, sizeof ctx->cam_R);
+    ctx->have_cam = true;
+    return RT_OK;
+}
+
+int rt_set_raygen(rt_ctx *ctx, int w, int h, double px, double y0, double dy, double z0, double dz)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (w < 1 || h < 1 || (long long)w * h > (1ll << 31)) return fail(ctx, RT_ERR_BAD_ARG, "frame size out of range");
+    ctx->w = w; ctx->h = h; ctx->px = px; ctx->y0 = y0; ctx->dy = dy; ctx->z0 = z0; ctx->dz = dz;
+    ctx->explicit_grid = false;
+    ctx->have_grid = true;
+    return RT_OK;
+}
+
+int rt_set_pixel_loc(rt_ctx *ctx, const double *pixel_loc, int w, int h)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!pixel_loc) return fail(ctx, RT_ERR_BAD_ARG, "pixel_loc is NULL");
+    if (w < 1 || h < 1 || (long long)w * h > (1ll << 31)) return fail(ctx, RT_ERR_BAD_ARG, "frame size out of range");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)3 * w * h * sizeof(double);
+    int rc = ensure(ctx, ctx->pixel_loc, bytes);
+    if (rc != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pixel_loc.p, pixel_loc, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->w = w; ctx->h = h;
+    ctx->explicit_grid = true;
+    ctx->have_grid = true;
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx *ctx, const rt_params *params, int x0, int x1, void *d_u8, void *d_f32, int64_t plane_stride, void *stream)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    int rc = check_params(ctx, params, x0, x1);
+    if (rc != RT_OK) return rc;
+    if (!d_u8 && !d_f32) return fail(ctx, RT_ERR_BAD_ARG, "both output pointers are NULL");
+    if (plane_stride < (int64_t)(x1 - x0) * ctx->h) return fail(ctx, RT_ERR_BAD_ARG, "plane_stride smaller than the slab");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return launch(ctx, params, x0, x1, d_u8, d_f32, plane_stride, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    int rc = check_params(ctx, params, x0, x1);
+    if (rc != RT_OK) return rc;
+    if (!out_u8 && !out_f32) return fail(ctx, RT_ERR_BAD_ARG, "both output pointers are NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)(x1 - x0) * ctx->h;
+    if (out_u8 && (rc = ensure(ctx, ctx->u8, 3 * npx)) != RT_OK) return rc;
+    if (out_f32 && (rc = ensure(ctx, ctx->f32, 3 * npx * sizeof(float))) != RT_OK) return rc;
+    rc = launch(ctx, params, x0, x1, out_u8 ? ctx->u8.p : nullptr, out_f32 ? ctx->f32.p : nullptr, (int64_t)npx, ctx->stream);
+    if (rc != RT_OK) return rc;
+    if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8, ctx->u8.p, 3 * npx, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32, ctx->f32.p, 3 * npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_malloc(rt_ctx *ctx, size_t bytes, void **dptr)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!dptr || bytes == 0) return fail(ctx, RT_ERR_BAD_ARG, "rt_malloc: NULL out-pointer or zero size");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMalloc(dptr, bytes));
+    return RT_OK;
+}
+
+int rt_free(rt_ctx *ctx, void *dptr)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!dptr) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipFree(dptr));
+    return RT_OK;
+}
+
+int rt_memcpy_h2d(rt_ctx *ctx, void *dst_device, const void *src_host, size_t bytes)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!dst_device || !src_host) return fail(ctx, RT_ERR_BAD_ARG, "rt_memcpy_h2d: NULL pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_memcpy_d2h(rt_ctx *ctx, void *dst_host, const void *src_device, size_t bytes)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!dst_host || !src_device) return fail(ctx, RT_ERR_BAD_ARG, "rt_memcpy_d2h: NULL pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_timer_begin(rt_ctx *ctx, void *stream)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, stream ? (hipStream_t)stream : ctx->stream));
+    return RT_OK;
+}
+
+int rt_timer_end(rt_ctx *ctx, void *stream, float *ms)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!ms) return fail(ctx, RT_ERR_BAD_ARG, "ms is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, stream ? (hipStream_t)stream : ctx->stream));
+    RT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    RT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RT_OK;
+}
+
+int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!info) return fail(ctx, RT_ERR_BAD_ARG, "info is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipFuncAttributes a;
+    RT_HIP(ctx, hipFuncGetAttributes(&a, (const void *)rt::render_kernel));
+    hipDeviceProp_t prop;
+    RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    std::memset(info, 0, sizeof *info);
+    info->vgprs = a.numRegs;
+    info->lds_static = (int32_t)a.sharedSizeBytes;
+    info->max_threads = a.maxThreadsPerBlock;
+    info->wave_size = prop.warpSize;
+    info->cu_count = prop.multiProcessorCount;
+    info->clock_khz = prop.clockRate;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""Stands where `from numba import cuda` stands in the reference's driver (main.py:2): the three
+names it uses — `to_device` (main.py:19-32), `DeviceNDArray.copy_to_host` (main.py:51) and
+`synchronize` (absent from the reference, which is why its timing is wrong).
+
+A DeviceNDArray keeps the host values it was created from (scene arrays and camera matrices are
+consumed by the C ABI as host pointers) and, once a launch has written to it, a device buffer that
+`copy_to_host()` reads back after synchronising — the launch itself is asynchronous, as in numba.
+"""
+import numpy as np
+
+from .renderer import Renderer
+
+_default = None
+
+
+def current_renderer(device=0):
+    """The process-wide context (numba's implicit CUDA context)."""
+    global _default
+    if _default is None:
+        _default = Renderer(device)
+    return _default
+
+
+def close():
+    global _default
+    if _default is not None:
+        _default.close()
+        _default = None
+
+
+class DeviceNDArray:
+    def __init__(self, host):
+        self._host = host            # values at creation time (inputs) / last copied-back values
+        self._dptr = None            # device buffer, allocated when a launch writes to this array
+        self._renderer = None
+        self._dirty = False          # device buffer newer than _host
+        self.version = 0             # bumped whenever the contents change (launch caches key on it)
+
+    shape = property(lambda self: self._host.shape)
+    dtype = property(lambda self: self._host.dtype)
+    ndim = property(lambda self: self._host.ndim)
+    nbytes = property(lambda self: self._host.nbytes)
+
+    def _device_buffer(self, renderer):
+        if self._dptr is None:
+            self._renderer = renderer
+            self._dptr = renderer.malloc(self._host.nbytes)
+        return self._dptr
+
+    def copy_to_host(self):
+        if self._dirty:
+            self._renderer.sync()
+            self._renderer.d2h(self._host, self._dptr)
+            self._dirty = False
+        return self._host.copy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.copy_to_host()
+        return a if dtype is None else a.astype(dtype)
+
+    def __del__(self):
+        try:
+            if self._dptr is not None:
+                self._renderer.free(self._dptr)
+        except Exception:
+            pass
+
+
+def to_device(a):
+    host = np.array(a, order="C")
+    # the pixel grid keeps its closed form, if it has one, so the kernel can generate rays itself
+    d = DeviceNDArray(host)
+    d.raygen = getattr(a, "raygen", None)
+    return d
+
+
+def device_array(shape, dtype=np.float64):
+    return DeviceNDArray(np.zeros(shape, dtype=dtype))
+
+
+def synchronize():
+    if _default is not None:
+        _default.sync()

@@ -1,0 +1,104 @@
+"""`render[blockspergrid, threadsperblock](pixel_loc, result, camera_origin, camera_rotation,
+spheres, lights, planes, amb, lamb, refl, refl_depth, aliasing)` — the call shape of the
+reference's numba kernel (kernels.py:7, launched at main.py:41-42), executed by the gfx950 HIP
+kernel in libmi355rt.so.
+
+Differences from a numba launch, all deliberate:
+  * grid/block only say which pixels are covered: x < gx*bx, y < gy*by, clipped to the frame
+    (the reference's `<=` guard would index one past the frame, kernels.py:13);
+  * `aliasing=True` renders the reference's 9-tap pattern on the interior and one tap on the
+    frame border, where the reference reads out of bounds (kernels.py:29).
+Arguments may be numpy arrays or `cuda.to_device` handles; `result` is written in place
+(asynchronously for a handle — `copy_to_host()` synchronises; synchronously for an ndarray).
+"""
+import numpy as np
+
+from .. import cuda as _cuda
+from .. import _lib as L
+
+
+def _host(a):
+    return a._host if isinstance(a, _cuda.DeviceNDArray) else np.asarray(a)
+
+
+class _Launch:
+    def __init__(self, kernel, griddim, blockdim):
+        self.kernel = kernel
+        try:
+            (gx, gy), (bx, by) = griddim, blockdim
+            self.cover = (int(gx) * int(bx), int(gy) * int(by))
+        except (TypeError, ValueError):
+            raise ValueError("render[grid, block]: grid and block must be 2-tuples of ints") from None
+        if min(self.cover) <= 0:
+            raise ValueError("render[grid, block]: empty launch")
+
+    def __call__(self, pixel_loc, result, camera_origin, camera_rotation, spheres, lights, planes,
+                 amb, lamb, refl, refl_depth, aliasing):
+        r = _cuda.current_renderer()
+        k = self.kernel
+        # -- inputs: re-sent only when the handles (or their contents' version) changed ----------
+        scene_key = tuple((id(a), getattr(a, "version", None)) for a in (spheres, lights, planes))
+        if any(v is None for _, v in scene_key) or scene_key != k._scene_key:
+            r.set_scene(_host(spheres), _host(lights), _host(planes), k.scene_flags)
+            k._scene_key = scene_key
+        r.set_camera(_host(camera_origin), _host(camera_rotation))
+        grid_key = (id(pixel_loc), getattr(pixel_loc, "version", None))
+        if grid_key[1] is None or grid_key != k._grid_key:
+            rg = getattr(pixel_loc, "raygen", None)
+            hp = _host(pixel_loc)
+            if hp.ndim != 3 or hp.shape[0] != 3:
+                raise ValueError(f"pixel_loc must have shape (3, w, h), got {hp.shape}")
+            if rg is not None:
+                r.set_raygen(hp.shape[1], hp.shape[2], *rg)
+            else:
+                r.set_pixel_loc(hp)
+            k._grid_key = grid_key
+        w, h = r.w, r.h
+        if tuple(result.shape) != (3, w, h) or result.dtype != np.uint8:
+            raise ValueError(f"result must be uint8 with shape (3, {w}, {h}), got {result.dtype} {tuple(result.shape)}")
+        if int(refl_depth) > L.RT_MAX_DEPTH:
+            raise ValueError(f"refl_depth > {L.RT_MAX_DEPTH}")
+        cx, cy = min(self.cover[0], w), min(self.cover[1], h)
+        p = r.params(amb, lamb, refl, refl_depth, bool(aliasing), k.render_flags)
+        if isinstance(result, _cuda.DeviceNDArray) and cy == h:
+            # asynchronous, in place: columns [0,cx) of the caller's device frame
+            if result._dptr is None and result._host.any():
+                r.h2d(result._device_buffer(r), result._host)
+            r.render_device(p, 0, cx, d_u8=result._device_buffer(r), plane_stride=w * h)
+            result._dirty = True
+            result.version += 1
+            return
+        # host ndarray result (or a launch that does not cover every row): synchronous
+        out8, _ = r.render(amb, lamb, refl, refl_depth, bool(aliasing), x0=0, x1=cx, flags=k.render_flags)
+        if isinstance(result, _cuda.DeviceNDArray):
+            host = result.copy_to_host()
+            host[:, :cx, :cy] = out8[:, :, :cy]
+            result._host[...] = host
+            if result._dptr is not None:
+                r.h2d(result._dptr, result._host)
+            result.version += 1
+        else:
+            result[:, :cx, :cy] = out8[:, :, :cy]
+
+
+class RenderKernel:
+    """The object the reference calls `render` (a numba CUDADispatcher there)."""
+
+    def __init__(self):
+        self.scene_flags = 0     # RT_FLAG_TYPED_BIAS to evaluate the plane BIAS*N product in float64
+        self.render_flags = 0    # RT_FLAG_U8_RGB for true (R,G,B) byte order
+        self._scene_key = None
+        self._grid_key = None
+
+    def __getitem__(self, cfg):
+        try:
+            griddim, blockdim = cfg
+        except (TypeError, ValueError):
+            raise ValueError("render[grid, block]: expected two launch dimensions") from None
+        return _Launch(self, griddim, blockdim)
+
+    def __call__(self, *a, **k):
+        raise TypeError("render must be configured first: render[blockspergrid, threadsperblock](...)")
+
+
+render = RenderKernel()

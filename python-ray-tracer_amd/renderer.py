@@ -1,0 +1,168 @@
+"""Renderer — thin object wrapper over the C ABI (include/mi355rt.h).  One Renderer = one rt_ctx
+= one GPU.  All pixel work happens in libmi355rt.so; this class only marshals arrays."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class RenderError(RuntimeError):
+    """A C-ABI call returned a non-zero rt_status."""
+
+    def __init__(self, status, message):
+        super().__init__(f"{L.STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def refl_powers(refl, depth):
+    """refl ** (i+1) evaluated on the host exactly as the reference does (trace.py:131)."""
+    out = np.zeros(L.RT_MAX_DEPTH, dtype=np.float64)
+    refl = float(refl)
+    for i in range(min(int(depth), L.RT_MAX_DEPTH)):
+        out[i] = refl ** (i + 1)
+    return out
+
+
+def _f32(a, rows, name):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[0] != rows:
+        raise ValueError(f"{name} must have shape ({rows}, N), got {a.shape}")
+    return a
+
+
+class Renderer:
+    def __init__(self, device=0):
+        self._lib = L.load()
+        self._ctx = C.c_void_p()
+        st = self._lib.rt_create(C.byref(self._ctx), int(device))
+        if st != L.RT_OK:
+            raise RenderError(st, self._lib.rt_last_error(None).decode())
+        self.device = int(device)
+        self.w = self.h = None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, st):
+        if st != L.RT_OK:
+            raise RenderError(st, self._lib.rt_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- inputs -----------------------------------------------------------------------------
+    def set_scene(self, spheres, lights, planes, flags=0):
+        """float32 (7,S), (3,L), (9,P) as Scene.generate_scene() returns them (scene/scene.py:96-97)."""
+        s, l, p = _f32(spheres, 7, "spheres"), _f32(lights, 3, "lights"), _f32(planes, 9, "planes")
+        fp = C.POINTER(C.c_float)
+        self._check(self._lib.rt_set_scene(self._ctx, s.ctypes.data_as(fp), s.shape[1], l.ctypes.data_as(fp), l.shape[1],
+                                           p.ctypes.data_as(fp), p.shape[1], int(flags)))
+        self.counts = (s.shape[1], l.shape[1], p.shape[1])
+
+    def set_camera(self, origin, rotation):
+        """camera_origin (3,), camera_rotation (3,3); forced to float64 (an all-int position list
+        would otherwise become int64)."""
+        o = np.ascontiguousarray(origin, dtype=np.float64).reshape(3)
+        r = np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.rt_set_camera(self._ctx, o.ctypes.data_as(dp), r.ctypes.data_as(dp)))
+
+    def set_raygen(self, w, h, px, y0, dy, z0, dz):
+        self._check(self._lib.rt_set_raygen(self._ctx, int(w), int(h), float(px), float(y0), float(dy), float(z0), float(dz)))
+        self.w, self.h = int(w), int(h)
+
+    def set_pixel_loc(self, pixel_loc):
+        a = np.ascontiguousarray(pixel_loc, dtype=np.float64)
+        if a.ndim != 3 or a.shape[0] != 3:
+            raise ValueError(f"pixel_loc must have shape (3, w, h), got {a.shape}")
+        self._check(self._lib.rt_set_pixel_loc(self._ctx, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[1], a.shape[2]))
+        self.w, self.h = a.shape[1], a.shape[2]
+
+    def set_grid(self, pixel_loc):
+        """Use the closed form when the array carries one (scene.camera.PixelGrid), else upload it."""
+        rg = getattr(pixel_loc, "raygen", None)
+        if rg is not None:
+            self.set_raygen(pixel_loc.shape[1], pixel_loc.shape[2], *rg)
+        else:
+            self.set_pixel_loc(pixel_loc)
+
+    @staticmethod
+    def params(amb, lamb, refl, depth, aa=False, flags=0, refl_pow=None):
+        p = L.rt_params()
+        p.amb, p.lamb = float(amb), float(lamb)
+        rp = refl_powers(refl, depth) if refl_pow is None else np.asarray(refl_pow, dtype=np.float64)
+        for i in range(min(len(rp), L.RT_MAX_DEPTH)):
+            p.refl_pow[i] = float(rp[i])
+        p.depth, p.aa_mode, p.flags = int(depth), (L.RT_AA_REFERENCE if aa else L.RT_AA_NONE), int(flags)
+        return p
+
+    # -- launches ---------------------------------------------------------------------------
+    def render(self, amb, lamb, refl, depth, aa=False, *, x0=0, x1=None, u8=True, f32=False, flags=0, refl_pow=None):
+        """Synchronous render of columns [x0,x1) into new host arrays of shape (3, x1-x0, h)."""
+        x1 = (self.w or 0) if x1 is None else int(x1)
+        p = self.params(amb, lamb, refl, depth, aa, flags, refl_pow)
+        n = max(x1 - int(x0), 0)     # a bad range still goes to the library, which reports it
+        out8 = np.empty((3, n, self.h or 0), np.uint8) if u8 else None
+        out32 = np.empty((3, n, self.h or 0), np.float32) if f32 else None
+        self._check(self._lib.rt_render(self._ctx, C.byref(p), int(x0), x1,
+                                        out8.ctypes.data if u8 else None, out32.ctypes.data if f32 else None))
+        return out8, out32
+
+    def render_device(self, params, x0, x1, d_u8=None, d_f32=None, plane_stride=None, stream=None):
+        """Asynchronous render into caller-owned device memory (raw addresses, e.g. tensor.data_ptr())."""
+        if plane_stride is None:
+            plane_stride = (int(x1) - int(x0)) * self.h
+        self._check(self._lib.rt_render_device(self._ctx, C.byref(params), int(x0), int(x1),
+                                               C.c_void_p(d_u8) if d_u8 else None, C.c_void_p(d_f32) if d_f32 else None,
+                                               int(plane_stride), C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        self._check(self._lib.rt_sync(self._ctx))
+
+    def timer_begin(self, stream=None):
+        self._check(self._lib.rt_timer_begin(self._ctx, C.c_void_p(stream) if stream else None))
+
+    def timer_end(self, stream=None):
+        ms = C.c_float()
+        self._check(self._lib.rt_timer_end(self._ctx, C.c_void_p(stream) if stream else None, C.byref(ms)))
+        return ms.value
+
+    def kernel_info(self):
+        info = L.rt_kernel_info()
+        self._check(self._lib.rt_get_kernel_info(self._ctx, C.byref(info)))
+        return {n: getattr(info, n) for n, _ in info._fields_ if n != "reserved"}
+
+    # -- raw device memory (used by the cuda facade) ------------------------------------------
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self._lib.rt_malloc(self._ctx, int(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        if dptr and self._ctx.value:
+            self._check(self._lib.rt_free(self._ctx, C.c_void_p(dptr)))
+
+    def h2d(self, dptr, host):
+        self._check(self._lib.rt_memcpy_h2d(self._ctx, C.c_void_p(dptr), host.ctypes.data, host.nbytes))
+
+    def d2h(self, host, dptr):
+        self._check(self._lib.rt_memcpy_d2h(self._ctx, host.ctypes.data, C.c_void_p(dptr), host.nbytes))
+
+
+def device_count():
+    n = C.c_int()
+    L.load().rt_device_count(C.byref(n))
+    return n.value

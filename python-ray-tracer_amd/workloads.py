@@ -1,0 +1,53 @@
+"""The synthetic workloads BASELINE.json names, as scene arrays in the reference's
+own formats.  Camera, shader scalars, lights and ground plane are the reference driver's literals
+(main.py:11,24; scene/scene.py:102-113).  tests/test_host_helpers.py checks these arrays against the
+committed golden fixtures, so bench.py, the tests and the goldens all describe the same scenes."""
+import numpy as np
+
+from .scene import Scene, Sphere, Camera
+from .scene.colors import RED, GREEN, BLUE, YELLOW, GREY, MAGENTA
+
+PALETTE = [RED, BLUE, YELLOW, MAGENTA, GREEN, GREY]
+CAMERA = dict(position=[-2, 0, 2.0], euler=[0, -30, 0], fov=45.0)          # main.py:24
+SHADER = dict(amb=0.0, lamb=0.6, refl=0.3)                                   # main.py:11
+EXTRA_SPHERES = [([0.9, -2.0, 0.6], 0.6, GREEN), ([3.5, -1.6, 0.8], 0.8, BLUE)]
+
+
+def grid_spheres(n_side, seed):
+    """n_side x n_side jittered grid of spheres resting on the ground plane (configs 4 and 5)."""
+    rng = np.random.default_rng(seed)
+    out, span_x, span_y = [], 9.0, 8.0
+    for i in range(n_side):
+        for j in range(n_side):
+            r = float(rng.integers(2, 9)) / 16.0 * (8.0 / n_side)
+            x = -0.5 + span_x * (i + 0.5) / n_side + float(rng.uniform(-0.25, 0.25)) * (8.0 / n_side)
+            y = -span_y / 2 + span_y * (j + 0.5) / n_side + float(rng.uniform(-0.25, 0.25)) * (8.0 / n_side)
+            out.append(Sphere([x, y, r], r, PALETTE[(i * n_side + j) % len(PALETTE)]))
+    return out
+
+
+def _scene(spheres):
+    base = Scene.default_scene()
+    return Scene(base.lights, spheres, base.planes)
+
+
+# name -> (w, h, depth, aa, scene factory, rays per frame {closest, shadow} or None)
+# Ray counts are the oracle's counters for the same frame (tests/test_oracle_golden.py re-derives C1/C2).
+CONFIGS = {
+    "c1_128x128_s3_d1": (128, 128, 1, False, lambda: _scene(Scene.default_scene().spheres[:3]), None),
+    "c2_1920x1080_s8_d3": (1920, 1080, 3, False,
+                           lambda: _scene(Scene.default_scene().spheres + [Sphere(*s) for s in EXTRA_SPHERES]),
+                           dict(closest=6309069, shadow=14017035)),
+    "c4_3840x2160_s64_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(8, 355)), None),
+    "c5_7680x4320_s256_d8": (7680, 4320, 8, False, lambda: _scene(grid_spheres(16, 356)), None),
+}
+HEADLINE = "c2_1920x1080_s8_d3"
+
+
+def build(name):
+    """-> dict(w, h, depth, aa, spheres, lights, planes, camera, rays)"""
+    w, h, depth, aa, make, rays = CONFIGS[name]
+    spheres, lights, planes = make().generate_scene()
+    cam = Camera(resolution=(w, h), **CAMERA)
+    return dict(name=name, w=w, h=h, depth=depth, aa=aa, spheres=spheres, lights=lights, planes=planes,
+                camera=cam, rays=rays, **SHADER)

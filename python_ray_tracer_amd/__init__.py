@@ -1,0 +1,9 @@
+"""Importable name for the package directory `python-ray-tracer_amd/` (a hyphen cannot appear in
+an `import` statement).  This module only redirects: all code lives in that directory."""
+import os as _os
+
+_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "python-ray-tracer_amd")
+__path__ = [_real]
+with open(_os.path.join(_real, "__init__.py")) as _f:
+    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+del _f

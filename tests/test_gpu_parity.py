@@ -1,0 +1,207 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes -> libmi355rt.so),
+against (1) the committed golden vectors produced by the reference's own Python and (2) the CPU
+oracle on the same inputs.  Bars: uint8 frame bit-exact; float32 pre-clip colour within 1e-5 abs of
+the reference's float64 value on the displayable range [0,255] (north_star tolerance) — and, since
+the kernel evaluates the same IEEE float64 operations, bit-equal to the oracle's float32 rounding."""
+import numpy as np
+import pytest
+
+from conftest import frame_cases, load_frame, raygen_closed_form, clamp255
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _setup(r, g, explicit_grid=False):
+    w, h = int(g["w"]), int(g["h"])
+    r.set_scene(g["spheres"], g["lights"], g["planes"])
+    r.set_camera(g["cam_origin"], g["cam_rot"])
+    rg = raygen_closed_form(w, h, float(g["fov"]))
+    if explicit_grid:
+        px, y0, dy, z0, dz = rg
+        grid = np.empty((3, w, h))
+        grid[0] = px
+        grid[1] = (np.arange(w) * dy + y0)[:, None]
+        grid[2] = (np.arange(h) * dz + z0)[None, :]
+        r.set_pixel_loc(grid)
+    else:
+        r.set_raygen(w, h, *rg)
+    return w, h, rg
+
+
+def _render(r, g, **kw):
+    return r.render(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), bool(g["aa"]),
+                    u8=True, f32=True, refl_pow=g["refl_pow"], **kw)
+
+
+SMALL = [c for c in frame_cases() if not c.startswith(("c2_", "c4_", "c5_"))]
+
+
+@pytest.mark.parametrize("case", SMALL)
+def test_frame_vs_golden(renderer, case):
+    g = load_frame(case)
+    _setup(renderer, g)
+    u8, f32 = _render(renderer, g)
+    co = g["coords"]
+    got8 = u8[:, co[:, 0], co[:, 1]].T
+    got32 = f32[:, co[:, 0], co[:, 1]].T.astype(np.float64)
+    assert np.array_equal(got8, g["u8"]), f"{(got8 != g['u8']).any(axis=1).sum()} of {len(co)} pixels differ (uint8)"
+    err = np.abs(clamp255(got32) - clamp255(g["rgb64"])).max()
+    assert err <= TOL, f"max abs err {err:.3e} > {TOL}"
+    # same float64 arithmetic => the float32 rounding of the reference's float64 value, exactly
+    assert np.array_equal(f32[:, co[:, 0], co[:, 1]].T, g["rgb64"].astype(np.float32))
+
+
+@pytest.mark.parametrize("case", ["c4_s64_d5_sub32", "c5_s256_d8_sub96"])
+def test_large_configs_sampled(renderer, case):
+    """BASELINE configs 4 and 5 (1 spp) at full resolution; golden = the reference on a pixel lattice."""
+    g = load_frame(case)
+    _setup(renderer, g)
+    u8, f32 = _render(renderer, g)
+    co = g["coords"]
+    assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, g["u8"])
+    assert np.array_equal(f32[:, co[:, 0], co[:, 1]].T, g["rgb64"].astype(np.float32))
+
+
+def test_c2_headline_frame_full(renderer, oracle):
+    """BASELINE config 2 (1920x1080, 8 spheres + plane, depth 3): every one of the 2 073 600 pixels
+    against the full uint8 frame the reference produced, plus the float lattice."""
+    import hashlib
+    g = load_frame("c2_1080p")
+    w, h, rg = _setup(renderer, g)
+    u8, f32 = _render(renderer, g)
+    assert np.array_equal(u8, g["frame_u8"]), f"{(u8 != g['frame_u8']).any(axis=0).sum()} pixels differ"
+    assert hashlib.sha256(u8.tobytes()).hexdigest() == str(g["sha256_u8"])
+    assert hashlib.sha256(f32.tobytes()).hexdigest() == str(g["sha256_rgb32"])
+    co = g["coords"]
+    err = np.abs(clamp255(f32[:, co[:, 0], co[:, 1]].T.astype(np.float64)) - clamp255(g["rgb64"])).max()
+    assert err <= TOL
+
+
+def test_explicit_pixel_loc_equals_raygen(renderer):
+    g = load_frame("odd_37x29")
+    _setup(renderer, g, explicit_grid=False)
+    a8, a32 = _render(renderer, g)
+    _setup(renderer, g, explicit_grid=True)
+    b8, b32 = _render(renderer, g)
+    assert np.array_equal(a8, b8) and np.array_equal(a32, b32)
+
+
+def test_explicit_pixel_loc_aa(renderer):
+    g = load_frame("aa_40x24_d1")
+    _setup(renderer, g, explicit_grid=True)
+    u8, f32 = _render(renderer, g)
+    co = g["coords"]
+    assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, g["u8"])
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])
+def test_column_slabs_assemble_bit_identical(renderer, nranks):
+    """Row-tiling used for multi-GPU: N column slabs rendered separately == the single-launch frame."""
+    from python_ray_tracer_amd.distributed import slab_bounds
+    g = load_frame("default_128_d3")
+    w, h, _ = _setup(renderer, g)
+    full8, full32 = _render(renderer, g)
+    parts = [_render(renderer, g, x0=a, x1=b) for a, b in (slab_bounds(w, nranks, r) for r in range(nranks))]
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), full8)
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=1), full32)
+
+
+def test_unaligned_slab(renderer):
+    g = load_frame("odd_37x29")
+    w, h, _ = _setup(renderer, g)
+    full8, _ = _render(renderer, g)
+    part8, _ = _render(renderer, g, x0=5, x1=18)
+    assert np.array_equal(part8, full8[:, 5:18])
+
+
+def test_u8_rgb_flag(renderer):
+    from python_ray_tracer_amd import _lib as L
+    g = load_frame("c1_128")
+    _setup(renderer, g)
+    a8, _ = _render(renderer, g)
+    b8, _ = _render(renderer, g, flags=L.RT_FLAG_U8_RGB)
+    assert np.array_equal(a8[[0, 2, 1]], b8)
+
+
+def test_typed_bias_flag_matches_oracle(renderer, oracle):
+    """The float64 BIAS*N variant (numba typing) is unpinned by the reference here; it must still
+    agree with the oracle's implementation of the same variant."""
+    from python_ray_tracer_amd import _lib as L
+    g = load_frame("tilted_planes_48")
+    w, h = int(g["w"]), int(g["h"])
+    renderer.set_scene(g["spheres"], g["lights"], g["planes"], flags=L.RT_FLAG_TYPED_BIAS)
+    renderer.set_camera(g["cam_origin"], g["cam_rot"])
+    rg = raygen_closed_form(w, h, float(g["fov"]))
+    renderer.set_raygen(w, h, *rg)
+    u8, f32 = _render(renderer, g)
+    ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]),
+                        float(g["lamb"]), float(g["refl"]), int(g["depth"]), False, raygen=rg, refl_pow=g["refl_pow"],
+                        flags=oracle.FLAG_TYPED_BIAS, want=("u8", "f32"))
+    assert np.array_equal(u8, ref["u8"]) and np.array_equal(f32, ref["f32"])
+
+
+def test_random_scenes_vs_oracle(renderer, oracle):
+    """Seeded random scenes (sizes the oracle finishes in seconds): bit-exact uint8 and float32."""
+    rng = np.random.default_rng(42)
+    for trial in range(6):
+        S, P, Ln = int(rng.integers(0, 40)), int(rng.integers(0, 4)), int(rng.integers(0, 6))
+        sp = np.zeros((7, S), np.float32)
+        sp[0:3] = rng.uniform(-4, 6, (3, S)); sp[3] = rng.uniform(0.1, 1.2, S); sp[4:7] = rng.integers(0, 256, (3, S))
+        pl = np.zeros((9, P), np.float32)
+        pl[0:3] = rng.uniform(-3, 3, (3, P))
+        n = rng.normal(size=(3, P)); pl[3:6] = n / np.linalg.norm(n, axis=0, keepdims=True); pl[6:9] = rng.integers(0, 256, (3, P))
+        li = rng.uniform(-6, 8, (3, Ln)).astype(np.float32)
+        w, h = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+        from python_ray_tracer_amd.scene import Camera
+        cam = Camera((w, h), list(rng.uniform(-3, 0, 3) + [0, 0, 2.5]), list(rng.uniform(-30, 30, 3)), fov=float(rng.uniform(30, 80)))
+        rg = cam.raygen()
+        amb, lamb, refl, depth, aa = float(rng.uniform(0, 0.3)), float(rng.uniform(0.2, 0.9)), float(rng.uniform(0, 0.8)), int(rng.integers(0, 7)), bool(trial % 2)
+        renderer.set_scene(sp, li, pl); renderer.set_camera(cam.position, cam.rotation); renderer.set_raygen(w, h, *rg)
+        u8, f32 = renderer.render(amb, lamb, refl, depth, aa, u8=True, f32=True)
+        ref = oracle.render(w, h, cam.position, cam.rotation, sp, li, pl, amb, lamb, refl, depth, aa, raygen=rg, want=("u8", "f32"))
+        assert np.array_equal(u8, ref["u8"]), f"trial {trial}: {(u8 != ref['u8']).any(axis=0).sum()} px differ"
+        assert np.array_equal(f32, ref["f32"]), f"trial {trial}"
+
+
+def test_facade_matches_reference_call_shape(renderer):
+    """The driver's call sequence (main.py:15-51) through the numba-shaped facade."""
+    from python_ray_tracer_amd import cuda
+    from python_ray_tracer_amd.ray_tracing import render
+    from python_ray_tracer_amd.scene import Scene, Camera
+    g = load_frame("default_128_d3")
+    w, h = 128, 128
+    spheres_host, light_host, planes_host = Scene.default_scene().generate_scene()
+    spheres, lights, planes = cuda.to_device(spheres_host), cuda.to_device(light_host), cuda.to_device(planes_host)
+    camera = Camera(resolution=(w, h), position=[-2, 0, 2.0], euler=[0, -30, 0])
+    camera_origin, camera_rotation = cuda.to_device(camera.position), cuda.to_device(camera.rotation)
+    pixel_loc = cuda.to_device(camera.generate_pixel_locations())
+    result = cuda.to_device(np.zeros((3, w, h), dtype=np.uint8))
+    threadsperblock = (16, 16)
+    blockspergrid = (int(np.ceil(w / 16)), int(np.ceil(h / 16)))
+    render[blockspergrid, threadsperblock](pixel_loc, result, camera_origin, camera_rotation,
+                                           spheres, lights, planes, 0.0, 0.6, 0.3, 3, False)
+    out = result.copy_to_host()
+    assert np.array_equal(out, g["frame_u8"])
+    # plain ndarrays + an explicit (untagged) pixel grid + a partial launch grid
+    res2 = np.zeros((3, w, h), np.uint8)
+    render[(4, 8), (16, 16)](np.array(camera.generate_pixel_locations()), res2, camera.position, camera.rotation,
+                             spheres_host, light_host, planes_host, 0.0, 0.6, 0.3, 3, False)
+    assert np.array_equal(res2[:, :64], g["frame_u8"][:, :64]) and not res2[:, 64:].any()
+
+
+def test_error_behaviour(renderer):
+    import python_ray_tracer_amd as pkg
+    r = pkg.Renderer(0)
+    with pytest.raises(pkg.RenderError) as e:
+        r.render(0.0, 0.6, 0.3, 1)
+    assert e.value.status == -4  # RT_ERR_STATE
+    g = load_frame("c1_128")
+    _setup(r, g)
+    with pytest.raises(pkg.RenderError):
+        r.render(0.0, 0.6, 0.3, 99)          # depth > RT_MAX_DEPTH
+    with pytest.raises(pkg.RenderError):
+        r.render(0.0, 0.6, 0.3, 1, x0=10, x1=5)
+    with pytest.raises(pkg.RenderError):
+        pkg.Renderer(10_000)                  # no such device
+    r.close()
