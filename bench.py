@@ -87,8 +87,14 @@ def main():
     ws = x1 - x0
     slab_u8 = torch.zeros((3, ws, h), dtype=torch.uint8, device=dev)
     slab_f32 = torch.zeros((3, ws, h), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream,
-    frame = None                                       # so the event pairs below bracket exactly the kernel
+    # The kernel is launched on a torch-owned, non-default stream that is also torch's current stream, so
+    # the event pairs below (and the gather's stream dependencies) bracket exactly the kernel.  (A NULL
+    # stream handed to rt_render_device would select the context's private stream instead.)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream, "expected a non-default stream handle"
+    frame = None
 
     def step(ev=None):
         nonlocal frame
