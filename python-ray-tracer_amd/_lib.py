@@ -51,18 +51,23 @@ PROTOTYPES = {
 _lib = None
 
 
+def bind(path):
+    """dlopen one build of the library and attach the prototypes (tools/ab_bench.py binds two builds)."""
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(or `make -C python-ray-tracer_amd/csrc`); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    if lib.rt_abi_version() != RT_ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}; rebuild")
+    return lib
+
+
 def load():
     """Load libmi355rt.so.  No fallback: a missing or stale library is an error."""
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise ImportError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                              f"(or `make -C python-ray-tracer_amd/csrc`); there is no CPU fallback")
-        lib = C.CDLL(SO_PATH)
-        for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(lib, name)          # AttributeError here = header/library mismatch
-            fn.restype, fn.argtypes = res, args
-        if lib.rt_abi_version() != RT_ABI_VERSION:
-            raise ImportError(f"{SO_PATH}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}; rebuild")
-        _lib = lib
+        _lib = bind(SO_PATH)
     return _lib

@@ -32,8 +32,8 @@ def _f32(a, rows, name):
 
 
 class Renderer:
-    def __init__(self, device=0):
-        self._lib = L.load()
+    def __init__(self, device=0, lib=None):
+        self._lib = lib if lib is not None else L.load()
         self._ctx = C.c_void_p()
         st = self._lib.rt_create(C.byref(self._ctx), int(device))
         if st != L.RT_OK:

@@ -1,0 +1,76 @@
+"""Multi-rank frame assembly on CPU (gloo, world_size 2 and 3): each rank produces its column slab
+(here with the CPU oracle standing in for the GPU kernel — the GPU slab path itself is covered by
+test_gpu_parity.py::test_column_slabs_assemble_bit_identical) and rank 0 must receive exactly the
+single-process frame through python_ray_tracer_amd.distributed.gather_frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_frame, raygen_closed_form
+
+
+def test_slab_bounds_partition():
+    from python_ray_tracer_amd.distributed import slab_bounds
+    for w in (1, 7, 8, 37, 128, 1920, 3840, 7680):
+        for n in (1, 2, 3, 4, 8):
+            b = [slab_bounds(w, n, r) for r in range(n)]
+            assert b[0][0] == 0 and b[-1][1] == w
+            assert all(b[i][1] == b[i + 1][0] for i in range(n - 1))
+            assert all(a % 8 == 0 for a, _ in b if a < w)
+            sizes = [y - x for x, y in b]
+            assert max(sizes) - min(sizes) <= 8 + 7
+    assert [slab_bounds(1920, 8, r) for r in range(8)] == [(240 * r, 240 * r + 240) for r in range(8)]
+    with pytest.raises(ValueError):
+        slab_bounds(64, 2, 2)
+
+
+def _worker(rank, world, port, case, out_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from python_ray_tracer_amd.distributed import slab_bounds, gather_frame
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = load_frame(case)
+    w, h = int(g["w"]), int(g["h"])
+    x0, x1 = slab_bounds(w, world, rank)
+    r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
+                   float(g["refl"]), int(g["depth"]), bool(g["aa"]), raygen=raygen_closed_form(w, h, float(g["fov"])),
+                   refl_pow=g["refl_pow"], x0=x0, x1=x1, want=("u8", "f32"), nthreads=2)
+    for key, dt in (("u8", torch.uint8), ("f32", torch.float32)):
+        slab = torch.from_numpy(np.ascontiguousarray(r[key][:, x0:x1]))
+        frame = gather_frame(slab, w, h, dist, dst=0)
+        if rank == 0:
+            np.save(out_path + f".{key}.npy", frame.numpy())
+        else:
+            assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,case", [(2, "default_128_d3"), (3, "odd_37x29"), (2, "nonsquare_40x24")])
+def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, case):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frame")
+    mp.spawn(_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
+    g = load_frame(case)
+    w, h = int(g["w"]), int(g["h"])
+    ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
+                        float(g["refl"]), int(g["depth"]), bool(g["aa"]), raygen=raygen_closed_form(w, h, float(g["fov"])),
+                        refl_pow=g["refl_pow"], want=("u8", "f32"))
+    assert np.array_equal(np.load(out + ".u8.npy"), ref["u8"])
+    assert np.array_equal(np.load(out + ".f32.npy"), ref["f32"])
+    co = g["coords"]
+    assert np.array_equal(ref["u8"][:, co[:, 0], co[:, 1]].T, g["u8"])
