@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libmi355rt.so")
+SO_PATH = os.environ.get("MI355RT_SO") or os.path.join(HERE, "libmi355rt.so")   # env override: A/B profiling of other builds
 
 RT_ABI_VERSION = 1
 RT_MAX_DEPTH = 16

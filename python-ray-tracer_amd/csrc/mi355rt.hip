@@ -30,6 +30,7 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
     int S = 0, P = 0, L = 0;
+    double scene_extent2 = 0.0;   // max squared distance of lights / sphere surfaces from the world origin
     bool have_scene = false, have_cam = false, have_grid = false, explicit_grid = false;
     double cam_o[3] = {0, 0, 0}, cam_R[9] = {0};
     int w = 0, h = 0;
@@ -105,7 +106,12 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.amb = p->amb; k.lamb = p->lamb;
     std::memcpy(k.refl_pow, p->refl_pow, sizeof k.refl_pow);
 
-    const size_t lds = sizeof(double) * ((size_t)ctx->S * rt::SPH_STRIDE + (size_t)ctx->P * rt::PL_STRIDE + (size_t)ctx->L * rt::LT_STRIDE);
+    // anchored cull table (camera + one anchor per light) if it fits its LDS budget, else origin-form culling only
+    const size_t table = (size_t)(ctx->L + 1) * ctx->S * rt::CULL_STRIDE * sizeof(float);
+    k.anchors = (table <= (size_t)rt::MAX_CULL_TABLE_BYTES) ? ctx->L + 1 : 0;
+    const double cam2 = ctx->cam_o[0] * ctx->cam_o[0] + ctx->cam_o[1] * ctx->cam_o[1] + ctx->cam_o[2] * ctx->cam_o[2];
+    k.extent2 = (float)(1.0001 * (cam2 > ctx->scene_extent2 ? cam2 : ctx->scene_extent2));
+    const size_t lds = rt::lds_bytes(ctx->S, ctx->P, ctx->L, k.anchors);
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         RT_HIP(ctx, hipFuncSetAttribute((const void *)rt::render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
@@ -214,6 +220,17 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
     } catch (const std::bad_alloc &) {
         return fail(ctx, RT_ERR_ALLOC, "out of host memory");
     }
+    double ext2 = 0.0;
+    for (int k = 0; k < S; ++k) {
+        const double cx = spheres[0 * S + k], cy = spheres[1 * S + k], cz = spheres[2 * S + k], r = std::fabs((double)spheres[3 * S + k]);
+        const double e = std::sqrt(cx * cx + cy * cy + cz * cz) + r;
+        if (e * e > ext2) ext2 = e * e;
+    }
+    for (int k = 0; k < L; ++k) {
+        const double x = lights[0 * L + k], y = lights[1 * L + k], z = lights[2 * L + k];
+        if (x * x + y * y + z * z > ext2) ext2 = x * x + y * y + z * z;
+    }
+    ctx->scene_extent2 = ext2;
     ctx->S = S; ctx->P = P; ctx->L = L;
     ctx->have_scene = true;
     return RT_OK;

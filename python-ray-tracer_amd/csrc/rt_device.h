@@ -11,17 +11,32 @@
 //   * the scene (float64-widened sphere/plane/light/material records, packed by the host) is
 //     staged once per workgroup into LDS and read with wave-uniform (broadcast) ds_reads;
 //   * every scene query normalises its direction ONCE (the reference re-normalises per sphere,
-//     intersections.py:13 — same value every time) and works on the quadratic scaled by 1/4,
-//     which is exact in binary floating point (see sphere_*() below);
+//     intersections.py:13 — same value every time), with an exact integer/FMA shortcut for
+//     already-unit vectors, and works on the quadratic scaled by 1/4 (exact in binary FP);
 //   * closest-hit keeps the smallest positive numerator and divides once per query;
 //   * shadow queries are any-hit: no sqrt/divide unless a decision is within rounding reach,
-//     and the sphere loop exits as soon as a wave ballot says every live lane is occluded;
+//     the sphere loop exits as soon as a wave ballot says every live lane is occluded, and
+//     lanes whose Lambert term is not positive (result unused, trace.py:101) do not query;
+//   * a conservative float32 pre-test ("cull") per sphere decides, for the whole wave, whether the
+//     float64 test can change anything; only spheres some lane might hit get the float64 test.
+//     The cull never decides a hit and never feeds a value into the result — it only skips
+//     float64 evaluations whose outcome (a miss) it has certified with an explicit error margin;
 //   * no MFMA: there is no dense contraction on this path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #pragma clang fp contract(off)
+
+#ifndef RT_PREFILTER
+#define RT_PREFILTER 1
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 6   // 80 VGPRs: 6 waves/SIMD measured faster than 5 (96) or 4 (105) despite a few spills
+#endif
+#ifndef RT_ABLATE
+#define RT_ABLATE 0   // diagnostic builds only: 1 = no shadow queries, 2 = cheap shading normalise, 3 = no sphere loop in closest hit
+#endif
 
 namespace rt {
 
@@ -31,6 +46,8 @@ constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 constexpr int SPH_STRIDE = 8;      // doubles per sphere record: cx,cy,cz,r2, R,G,B,pad
 constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, R,G,B,pad
 constexpr int LT_STRIDE = 4;       // x,y,z,pad
+constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, w+margin (one ds_read_b128)
+constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
 
 struct KParams {
     const double *scene;       // packed records: S spheres, then P planes, then L lights
@@ -41,6 +58,8 @@ struct KParams {
     int w, h, x0, x1;
     int S, P, L, depth;
     int aa, u8_rgb, tiles_y, ntiles;
+    int anchors, pad0;         // L+1 if the anchored cull table is in use, else 0
+    float extent2, pad1;       // max squared distance of camera / lights / sphere surfaces from the world origin
     double px, y0, dy, z0, dz;
     double cam_o[3];
     double cam_R[9];
@@ -49,14 +68,20 @@ struct KParams {
 };
 
 struct V3 { double x, y, z; };
+struct F3 { float x, y, z; };
 
 __device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // common.py:35-37
 
 // common.py:28-32 — three true divisions, not a multiply by the reciprocal.
 __device__ __forceinline__ V3 normalize3(const V3 &v)
 {
+#if RT_ABLATE == 2
+    double n = 1.0 / (float)(v.x * v.x + v.y * v.y + v.z * v.z);   // diagnostic: wrong on purpose, cheap
+    return V3{v.x * n, v.y * n, v.z * n};
+#else
     double n = __builtin_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
     return V3{v.x / n, v.y / n, v.z / n};
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -97,6 +122,112 @@ __device__ __forceinline__ V3 renormalize_unit(const V3 &d)
 enum { HIT_NONE = 0, HIT_SPHERE = 1, HIT_PLANE = 2 };
 
 // ---------------------------------------------------------------------------------------------
+// Conservative float32 cull.  For a ray (o, R) and sphere (c, r2) the reference computes, in
+// float64, D = s² - a·(|L|² - r2) with L = o - c, s = L·R, and reports a miss when D < 0, or when
+// s >= 0 and |L|² - r2 >= 0 ("behind", see below).  D is r2 minus the squared distance from c to
+// the ray's LINE, so it may be evaluated from any point A of the line: D = (A-c)·R)² - |A-c|² + r2.
+//
+//  * anchored form — every primary ray passes through the camera and every shadow ray through its
+//    light, so with A = camera/light the vector A-c, w = r2-|A-c|² and the error margin are
+//    constants per (anchor, sphere): a table built once per workgroup in LDS (from float64), and
+//    the per-ray work is s' = (A-c)·R32 (3 ops), D' = fma(s',s',w), one compare;
+//  * origin form — for reflection rays, and for the sphere a shadow ray starts on, L = o32 - c is
+//    formed per lane; it also certifies "behind" (s > e_s and |L|²-r2 > e_c).
+//
+// Error budget, u = 2^-24, Λ = |A-c| or |L|: inputs rounded to float32 (relative u each), three
+// roundings in each dot product, one in the final fma:
+//     anchored: |D' - D| <= u(13Λ² + 2 r2)               margin used: 32u(Λ² + r2)
+//     origin:   |D' - D| <= u(19Λ² + 2|o|² + 2 r2)       margin used: 64u(Λ² + |o|² + r2)
+//               |s' - s| <= u(|o| + 5Λ)                  margin used:  8u(1 + Λ² + |o|²)
+//               |c' - c| <= u(7Λ² + |o|² + r2)           margin used: 64u(Λ² + |o|² + r2)
+// plus, in all of them, floor = 2^-40(|o|² + extent²) >= the float64 rounding of the reference's own
+// D (<= 2^-50 of its operands) and the distance by which a float64 direction misses its anchor.
+// A sphere is skipped only if EVERY live lane holds a certificate; NaNs certify nothing.
+// ---------------------------------------------------------------------------------------------
+constexpr float CULL_K_ANCHOR = 0x1p-19f * 1.0001f;
+constexpr float CULL_K_ORIGIN = 0x1p-18f;
+constexpr float CULL_K_S = 0x1p-21f;
+constexpr float CULL_K_FLOOR = 0x1p-40f;
+
+struct Lds {
+    const double *rec;     // float64 records
+    const float *sph32;    // S x {cx,cy,cz,r2}
+    const float *tab;      // anchors x S x CULL_STRIDE
+};
+
+struct RayF {              // float32 shadow of a query, for the cull only
+    F3 o, R;
+    float oo, floorq;
+};
+
+__device__ __forceinline__ RayF make_rayf(const V3 &o, const V3 &R, float extent2)
+{
+    RayF q;
+    q.o = F3{(float)o.x, (float)o.y, (float)o.z};
+    q.R = F3{(float)R.x, (float)R.y, (float)R.z};
+    q.oo = __builtin_fmaf(q.o.z, q.o.z, __builtin_fmaf(q.o.y, q.o.y, q.o.x * q.o.x));
+    q.floorq = CULL_K_FLOOR * (q.oo + extent2);
+    return q;
+}
+
+// true = this lane holds a certificate that sphere k reports a miss for this ray (anchored form)
+__device__ __forceinline__ bool cull_anchored(const float *__restrict__ e, const RayF &q)
+{
+    const float s = __builtin_fmaf(e[2], q.R.z, __builtin_fmaf(e[1], q.R.y, e[0] * q.R.x));
+    const float D = __builtin_fmaf(s, s, e[3]);               // e[3] = r2 - |A-c|² + margin
+    return D < -q.floorq;
+}
+
+// Phase 1 of a scene query: one bit per sphere of the chunk [k0, k0+n), set when SOME live lane holds
+// no certificate.  Straight-line float32 work with no dependence between spheres; the mask is
+// wave-uniform (it is built from ballots), so phase 2 — the float64 test — runs only for set bits.
+// self / self_culled: the sphere a shadow ray starts on and its origin-form certificate.
+__device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
+                                                        const RayF &q, int self, bool self_culled);
+
+// origin form: line-miss or behind certificate
+__device__ __forceinline__ bool cull_origin(const float *__restrict__ c, const RayF &q)
+{
+    const float lx = q.o.x - c[0], ly = q.o.y - c[1], lz = q.o.z - c[2];
+    const float s = __builtin_fmaf(lz, q.R.z, __builtin_fmaf(ly, q.R.y, lx * q.R.x));
+    const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+    const float cc = ll - c[3];
+    const float D = __builtin_fmaf(s, s, -cc);
+    const float mg = __builtin_fmaf(CULL_K_ORIGIN, (ll + q.oo) + c[3], q.floorq);
+    const float es = CULL_K_S * ((1.0f + ll) + q.oo);
+    return (D < -mg) || (s > es && cc > mg);
+}
+
+__device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
+                                                        const RayF &q, int self, bool self_culled)
+{
+    unsigned long long mask = 0ull;
+    // manual 4-way unroll: indices past the chunk are clamped (they recompute the last sphere's bit)
+    if (anchor >= 0) {
+        const float *tab = lds.tab + ((size_t)anchor * S + k0) * CULL_STRIDE;
+        for (int j = 0; j < n; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = (j + u < n) ? j + u : n - 1;
+                const bool culled = cull_anchored(tab + jj * CULL_STRIDE, q) || (self_culled && (k0 + jj) == self);
+                mask |= (__ballot(!culled) != 0ull ? 1ull : 0ull) << jj;
+            }
+        }
+    } else {
+        const float *sp = lds.sph32 + 4 * k0;
+        for (int j = 0; j < n; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = (j + u < n) ? j + u : n - 1;
+                const bool culled = cull_origin(sp + 4 * jj, q);
+                mask |= (__ballot(!culled) != 0ull ? 1ull : 0ull) << jj;
+            }
+        }
+    }
+    return mask;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Sphere test, intersections.py:6-38, restated on the quadratic divided by 4.
 //   reference:  b = 2s, disc = b*b - (4a)*c, num = -b -/+ sqrt(disc), t = num / (2a)
 //   here:       D = s*s - a*c,  q = sqrt(D),  n = -s -/+ q,           t = n / a
@@ -107,15 +238,31 @@ enum { HIT_NONE = 0, HIT_SPHERE = 1, HIT_PLANE = 2 };
 // ---------------------------------------------------------------------------------------------
 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
-__device__ __forceinline__ void closest_hit(const double *__restrict__ lds, int S, int P, const V3 &o, const V3 &d,
+// anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
+// or -1 for rays with no common anchor (reflections).
+__device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
                                             double &t_out, int &idx_out, int &type_out)
 {
+    const int S = p.S, P = p.P;
     const V3 R = renormalize_unit(d);                         // == normalize(d), intersections.py:13
     const double a = dot3(R, R);
+#if RT_PREFILTER
+    const RayF qf = make_rayf(o, R, p.extent2);
+    const int canchor = (p.anchors > 0) ? anchor : -1;
+#endif
     double bestn = __builtin_inf();
     int bidx = -1;
-    for (int k = 0; k < S; ++k) {
-        const double *g = lds + k * SPH_STRIDE;
+    for (int k0 = 0; k0 < (RT_ABLATE == 3 ? 0 : S); k0 += 64) {
+      const int n = (S - k0 < 64) ? S - k0 : 64;
+#if RT_PREFILTER
+      unsigned long long mask = cull_mask(lds, S, canchor, k0, n, qf, -1, false);
+#else
+      unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+#endif
+      while (mask) {                                          // spheres some live lane might hit, ascending
+        const int k = k0 + __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        const double *g = lds.rec + k * SPH_STRIDE;
         const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};     // :16
         const double s = dot3(Lv, R);                         // b/2
         const double cc = dot3(Lv, Lv) - g[3];                // :21 (g[3] = float32 r*r, widened)
@@ -126,6 +273,7 @@ __device__ __forceinline__ void closest_hit(const double *__restrict__ lds, int 
             if (!(n > 0.0)) n = -s + q;                       // :33
             if (n > 0.0 && n < bestn) { bestn = n; bidx = k; }   // first smallest wins (strict <), trace.py:26
         }
+      }
     }
     double best = 999.0;                                      // trace.py:17
     int idx = -1, type = HIT_NONE;
@@ -133,7 +281,7 @@ __device__ __forceinline__ void closest_hit(const double *__restrict__ lds, int 
         const double t = bestn / a;                           // :31 / :36, once per query
         if (best > t && t > 0.0) { best = t; idx = bidx; type = HIT_SPHERE; }
     }
-    const double *pl = lds + S * SPH_STRIDE;
+    const double *pl = lds.rec + S * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {                             // intersections.py:41-68
         const double *g = pl + k * PL_STRIDE;
         const V3 n{g[3], g[4], g[5]};
@@ -149,16 +297,35 @@ __device__ __forceinline__ void closest_hit(const double *__restrict__ lds, int 
 
 // trace.py:92-96: the shadow query only asks "does anything report 0 < t < 999" (any hit).
 // Called with the lanes that need the answer active; returns true if occluded.
-__device__ __forceinline__ bool any_hit(const double *__restrict__ lds, int S, int P, const V3 &o, const V3 &d)
+// anchor = cull-table index of the light the ray points at; self = index of the sphere the ray
+// starts on (-1: a plane), whose miss is certified by the origin-form "behind" test.
+__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self)
 {
+    const int S = p.S, P = p.P;
     const V3 R = renormalize_unit(d);                         // == normalize(d), intersections.py:13
     const double a = dot3(R, R);
     const bool a_sane = (a > 0.999999 && a < 1.000001);
     bool occ = false;
-    for (int k = 0; k < S; ++k) {
+#if RT_PREFILTER
+    const RayF qf = make_rayf(o, R, p.extent2);
+    const int canchor = (p.anchors > 0) ? anchor : -1;
+    bool self_culled = false;
+    if (canchor >= 0 && self >= 0) self_culled = cull_origin(lds.sph32 + 4 * self, qf);
+#endif
+    for (int k0 = 0; k0 < S; k0 += 64) {
+      if (__ballot(!occ) == 0ull) break;
+      const int n = (S - k0 < 64) ? S - k0 : 64;
+#if RT_PREFILTER
+      unsigned long long mask = cull_mask(lds, S, canchor, k0, n, qf, self, self_culled);
+#else
+      unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+#endif
+      while (mask) {
         if (__ballot(!occ) == 0ull) break;                    // every live lane already occluded
+        const int k = k0 + __builtin_ctzll(mask);
+        mask &= mask - 1ull;
         if (!occ) {
-            const double *g = lds + k * SPH_STRIDE;
+            const double *g = lds.rec + k * SPH_STRIDE;
             const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};
             const double s = dot3(Lv, R);
             const double cc = dot3(Lv, Lv) - g[3];
@@ -180,8 +347,9 @@ __device__ __forceinline__ bool any_hit(const double *__restrict__ lds, int S, i
                 }
             }
         }
+      }
     }
-    const double *pl = lds + S * SPH_STRIDE;
+    const double *pl = lds.rec + S * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {
         if (__ballot(!occ) == 0ull) break;
         if (!occ) {
@@ -207,55 +375,64 @@ __device__ __forceinline__ bool any_hit(const double *__restrict__ lds, int S, i
 
 // trace.py:44-112.  On entry `alive` lanes carry a ray (o,d); on exit `alive` is false for lanes
 // that missed (the reference's 404 sentinels), rgb is this bounce's colour, (o,d) the next ray.
-__device__ __forceinline__ void trace_bounce(const double *__restrict__ lds, const KParams &p, bool &alive,
+__device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                              V3 &o, V3 &d, V3 &rgb)
 {
     const int S = p.S, P = p.P, L = p.L;
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
-    if (alive) closest_hit(lds, S, P, o, d, t, idx, type);                    // :53 (idle lanes masked off)
+    if (alive) closest_hit(lds, p, o, d, anchor, t, idx, type);               // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     if (alive) {
         V3 Pt{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                   // :60 (1.0*o is exact)
         V3 col, N, bN;
         if (type == HIT_SPHERE) {                                             // :63-66
-            const double *g = lds + idx * SPH_STRIDE;
+            const double *g = lds.rec + idx * SPH_STRIDE;
             col = V3{g[4], g[5], g[6]};
             N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});        // common.py:94-101
             bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
         } else {                                                              // :68-71
-            const double *g = lds + S * SPH_STRIDE + idx * PL_STRIDE;
+            const double *g = lds.rec + S * SPH_STRIDE + idx * PL_STRIDE;
             N = V3{g[6], g[7], g[8]};                                         // float32-renormalised, host-side
             bN = V3{g[9], g[10], g[11]};                                      // BIAS*N as the reference rounds it
             col = V3{g[12], g[13], g[14]};
         }
         rgb = V3{p.amb * col.x, p.amb * col.y, p.amb * col.z};                // :77 (0 + amb*col)
         Pt = V3{Pt.x + bN.x, Pt.y + bN.y, Pt.z + bN.z};                       // :82-83
-        const double *lt = lds + S * SPH_STRIDE + P * PL_STRIDE;
+        const int self = (type == HIT_SPHERE) ? idx : -1;
+        const double *lt = lds.rec + S * SPH_STRIDE + P * PL_STRIDE;
         for (int m = 0; m < L; ++m) {                                         // :86-102
             const double *g = lt + m * LT_STRIDE;
             const V3 Ld = normalize3(V3{g[0] - Pt.x, g[1] - Pt.y, g[2] - Pt.z});   // common.py:84-91
-            const bool occluded = any_hit(lds, S, P, Pt, Ld);                 // :92-96
             const double k = p.lamb * dot3(Ld, N);                            // :99
-            if (!occluded && k > 0.0) {                                       // :101-102
-                rgb = V3{rgb.x + k * col.x, rgb.y + k * col.y, rgb.z + k * col.z};
+            // :92-102 — the shadow query's answer is only used when k > 0; it has no other effect,
+            // so lanes with k <= 0 (light behind the surface) do not ask.
+            if (k > 0.0) {
+#if RT_ABLATE == 1
+                const bool occluded = false;
+#else
+                const bool occluded = any_hit(lds, p, Pt, Ld, 1 + m, self);
+#endif
+                if (!occluded) rgb = V3{rgb.x + k * col.x, rgb.y + k * col.y, rgb.z + k * col.z};
             }
         }
         const double c2 = -2.0 * dot3(d, N);                                  // common.py:113-120
-        const V3 Rd = normalize3(V3{d.x + c2 * N.x, d.y + c2 * N.y, d.z + c2 * N.z});
+        // |d - 2(d.N)N| = 1 up to rounding for unit d, N: the exact unit-vector path applies (it falls
+        // back to sqrt-and-divide by itself otherwise)
+        const V3 Rd = renormalize_unit(V3{d.x + c2 * N.x, d.y + c2 * N.y, d.z + c2 * N.z});
         o = V3{Pt.x + 0.0002 * Rd.x, Pt.y + 0.0002 * Rd.y, Pt.z + 0.0002 * Rd.z};   // :110
         d = Rd;
     }
 }
 
-// trace.py:115-133
-__device__ __forceinline__ V3 sample(const double *__restrict__ lds, const KParams &p, bool alive, V3 o, V3 d)
+// trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
+__device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d)
 {
     V3 acc{0.0, 0.0, 0.0};
     for (int b = 0; b <= p.depth; ++b) {
         if (__ballot(alive) == 0ull) break;                                   // wave-uniform exit
         V3 rgb;
-        trace_bounce(lds, p, alive, o, d, rgb);
+        trace_bounce(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
         if (b == 0) acc = rgb;                                                // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
             const double wgt = p.refl_pow[b - 1];
@@ -292,18 +469,50 @@ __device__ __forceinline__ uint8_t clip_color(double c)
     return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
 }
 
-__global__ __launch_bounds__(WG_THREADS) void render_kernel(const KParams p)
+// LDS image: [float64 records][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
+__host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors)
 {
-    extern __shared__ double lds[];
+    return lds_doubles(S, P, L) * sizeof(double) + (size_t)S * 4 * sizeof(float) + (size_t)anchors * S * CULL_STRIDE * sizeof(float);
+}
+
+__global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(const KParams p)
+{
+    extern __shared__ double lds_raw[];
+    const int nrec = (int)lds_doubles(p.S, p.P, p.L);
+    float *sph32 = reinterpret_cast<float *>(lds_raw + nrec);
+    float *tab = sph32 + 4 * p.S;
     {   // stage the packed scene once per workgroup
-        const int n = p.S * SPH_STRIDE + p.P * PL_STRIDE + p.L * LT_STRIDE;
-        for (int i = threadIdx.x; i < n; i += WG_THREADS) lds[i] = p.scene[i];
+        for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
     }
     __syncthreads();
+#if RT_PREFILTER
+    {   // float32 sphere table (exact: the scene is float32) and the anchored cull table
+        for (int k = threadIdx.x; k < p.S; k += WG_THREADS) {
+            const double *g = lds_raw + k * SPH_STRIDE;
+            sph32[4 * k + 0] = (float)g[0]; sph32[4 * k + 1] = (float)g[1]; sph32[4 * k + 2] = (float)g[2]; sph32[4 * k + 3] = (float)g[3];
+        }
+        const double *lt = lds_raw + p.S * SPH_STRIDE + p.P * PL_STRIDE;
+        for (int e = threadIdx.x; e < p.anchors * p.S; e += WG_THREADS) {
+            const int a = e / p.S, k = e - a * p.S;
+            const double *g = lds_raw + k * SPH_STRIDE;
+            const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
+            const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
+            const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
+            const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
+            const double ll = lx * lx + ly * ly + lz * lz;
+            float *t = tab + (size_t)e * CULL_STRIDE;
+            t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
+            t[3] = (float)((g[3] - ll) + (ll + g[3]) * (double)CULL_K_ANCHOR);     // w + margin
+        }
+    }
+    __syncthreads();
+#endif
+    const Lds lds{lds_raw, sph32, tab};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * WAVES_PER_WG + wave;
-    if (tile >= p.ntiles) return;                                             // whole wave, after the barrier
+    if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
     const int x = p.x0 + tx * TILE + (lane >> 3);
     const int y = ty * TILE + (lane & 7);
