@@ -68,7 +68,7 @@ def main():
     import torch.distributed as dist
     import python_ray_tracer_amd as pkg
     from python_ray_tracer_amd import workloads
-    from python_ray_tracer_amd.distributed import slab_bounds, gather_frame
+    from python_ray_tracer_amd.distributed import slab_bounds, FrameGatherer
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -85,8 +85,6 @@ def main():
     params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"])
     x0, x1 = slab_bounds(w, world, rank)
     ws = x1 - x0
-    slab_u8 = torch.zeros((3, ws, h), dtype=torch.uint8, device=dev)
-    slab_f32 = torch.zeros((3, ws, h), dtype=torch.float32, device=dev)
     # The kernel is launched on a torch-owned, non-default stream that is also torch's current stream, so
     # the event pairs below (and the gather's stream dependencies) bracket exactly the kernel.  (A NULL
     # stream handed to rt_render_device would select the context's private stream instead.)
@@ -94,19 +92,38 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream, "expected a non-default stream handle"
+    SLOTS = 2                                           # frame i is gathered while frame i+1 renders
+    slabs_u8 = [torch.zeros((3, ws, h), dtype=torch.uint8, device=dev) for _ in range(SLOTS)]
+    slab_f32 = torch.zeros((3, ws, h), dtype=torch.float32, device=dev)
+    gatherer = FrameGatherer(w, h, torch.uint8, dev, dist, dst=0, slots=SLOTS) if world > 1 else None
+    busy = [False] * SLOTS
     frame = None
 
-    def step(ev=None):
+    def step(i, ev=None):
         nonlocal frame
+        b = i % SLOTS
+        if gatherer is not None and busy[b]:            # the slab is reused: its gather must have completed
+            f = gatherer.finish(b)
+            frame = f if f is not None else frame
+            busy[b] = False
         if ev:
             ev[0].record()
-        r.render_device(params, x0, x1, slab_u8.data_ptr(), slab_f32.data_ptr(), ws * h, stream)
+        r.render_device(params, x0, x1, slabs_u8[b].data_ptr(), slab_f32.data_ptr(), ws * h, stream)
         if ev:
             ev[1].record()
-        if world > 1:
-            frame = gather_frame(slab_u8, w, h, dist, dst=0)
+        if gatherer is not None:
+            gatherer.submit(slabs_u8[b], b)
+            busy[b] = True
         else:
-            frame = slab_u8
+            frame = slabs_u8[b]
+
+    def drain():
+        nonlocal frame
+        for b in range(SLOTS):
+            if gatherer is not None and busy[b]:
+                f = gatherer.finish(b)
+                frame = f if f is not None else frame
+                busy[b] = False
 
     def fence():
         torch.cuda.synchronize()
@@ -114,13 +131,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(events[i])
+        step(i, events[i])
+    drain()                                             # every one of the K frames is assembled on rank 0
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(a.steps, 1)
@@ -161,7 +180,7 @@ def main():
             "config": {"workload": name, "width": w, "height": h, "spheres": S, "planes": P, "lights": L,
                        "depth": wl["depth"], "aa": bool(wl["aa"]), "rays_per_frame": rays_per_frame,
                        "primary_rays_per_frame": w * h, "outputs": "uint8 (3,w,h) frame + float32 (3,w,h) pre-clip RGB",
-                       "parallelism": f"column slabs x{world}" + (", RCCL gather of the uint8 frame to rank 0" if world > 1 else "")},
+                       "parallelism": f"column slabs x{world}" + (", one RCCL gather of the uint8 frame to rank 0 per step, overlapped with the next step's render" if world > 1 else "")},
             "frame_ms": round(ms_per_step, 5),
             "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
             "frame_matches_reference_sha256": check,

@@ -3,9 +3,11 @@ column slab per rank (every pixel is independent — kernels.py:10-26 — and th
 each rank renders its slab with its own x offset, and the frame is assembled on rank 0 by a gather
 (RCCL over xGMI when the process group is `nccl`; `gloo` on CPU for tests).
 
-Because the frame is C-ordered with x as the slower spatial axis, rank r's part of colour plane c is
-one contiguous run of (x1-x0)*h elements at offset c*w*h + x0*h, so each plane is gathered straight
-into place with no permutation pass afterwards.
+With equal slabs (w divisible by 8*world, e.g. 1920 on 1/2/4/8 GPUs) the exchange is ONE gather per
+frame into a (world, 3, ws, h) staging buffer followed by one strided device copy into the (3,w,h)
+frame; it can be issued asynchronously so that frame i is gathered while frame i+1 is rendered
+(FrameGatherer, double-buffered).  Ragged slabs fall back to per-plane point-to-point transfers
+straight into the frame's contiguous column runs.
 """
 
 
@@ -21,32 +23,68 @@ def slab_bounds(w, world_size, rank, align=8):
     return min(t0 * align, w), min(t1 * align, w)
 
 
+class FrameGatherer:
+    """Assembles per-rank slabs of shape (3, x1-x0, h) into (3,w,h) frames on rank `dst`.
+
+    submit(slab, slot) starts the exchange for one frame (asynchronously where the backend allows) and
+    finish(slot) completes it and returns the frame on `dst` (None elsewhere).  `slots` frames may be in
+    flight; a slot's slab must not be overwritten between its submit() and finish()."""
+
+    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2):
+        import torch
+        self.torch, self.dist, self.dst = torch, dist, dst
+        self.w, self.h = w, h
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.bounds = [slab_bounds(w, self.world, r) for r in range(self.world)]
+        widths = {b - a for a, b in self.bounds}
+        self.equal = len(widths) == 1
+        self.ws = self.bounds[self.rank][1] - self.bounds[self.rank][0]
+        self.pending = [None] * slots
+        self.frames = self.stage = None
+        if self.rank == dst:
+            self.frames = [torch.empty((3, w, h), dtype=dtype, device=device) for _ in range(slots)]
+            if self.equal:
+                self.stage = [torch.empty((self.world, 3, self.ws, h), dtype=dtype, device=device) for _ in range(slots)]
+
+    def submit(self, slab, slot):
+        assert self.pending[slot] is None, "slot still in flight: call finish(slot) first"
+        assert tuple(slab.shape) == (3, self.ws, self.h) and slab.is_contiguous()
+        dist, root = self.dist, self.rank == self.dst
+        if self.equal:
+            recv = [self.stage[slot][r] for r in range(self.world)] if root else None
+            self.pending[slot] = ("gather", dist.gather(slab, recv, dst=self.dst, async_op=True))
+            return
+        reqs = []                                       # ragged: plane-wise straight into the frame
+        for c in range(3):
+            if root:
+                for r, (a, b) in enumerate(self.bounds):
+                    if r == self.dst:
+                        self.frames[slot][c, a:b].copy_(slab[c])
+                    elif b > a:
+                        reqs.append(dist.irecv(self.frames[slot][c, a:b], src=r))
+            elif self.ws:
+                reqs.append(dist.isend(slab[c], dst=self.dst))
+        self.pending[slot] = ("p2p", reqs)
+
+    def finish(self, slot):
+        kind, work = self.pending[slot]
+        self.pending[slot] = None
+        if kind == "gather":
+            work.wait()
+            if self.rank != self.dst:
+                return None
+            f = self.frames[slot]
+            f.view(3, self.world, self.ws, self.h).copy_(self.stage[slot].permute(1, 0, 2, 3))
+            return f
+        for q in work:
+            q.wait()
+        return self.frames[slot] if self.rank == self.dst else None
+
+
 def gather_frame(slab, w, h, dist, dst=0):
-    """Gather per-rank slabs (torch tensors of shape (3, x1-x0, h)) into a (3,w,h) frame on `dst`.
-    One gather per colour plane, each receiving directly into the frame's contiguous column run."""
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    if world == 1:
+    """Synchronous convenience wrapper: gather one frame; returns it on `dst`, None elsewhere."""
+    if dist.get_world_size() == 1:
         return slab
-    frame = None
-    if rank == dst:
-        frame = torch.empty((3, w, h), dtype=slab.dtype, device=slab.device)
-    for c in range(3):
-        recv = None
-        if rank == dst:
-            recv = [frame[c, a:b] for a, b in (slab_bounds(w, world, r) for r in range(world))]
-        if all(b - a == slab.shape[1] for a, b in (slab_bounds(w, world, r) for r in range(world))):
-            dist.gather(slab[c].contiguous(), recv, dst=dst)
-        else:  # ragged slabs: gather requires equal sizes, so fall back to point-to-point
-            if rank == dst:
-                reqs = []
-                for r in range(world):
-                    if r == dst:
-                        recv[r].copy_(slab[c])
-                    elif recv[r].numel():
-                        reqs.append(dist.irecv(recv[r], src=r))
-                for q in reqs:
-                    q.wait()
-            elif slab[c].numel():
-                dist.send(slab[c].contiguous(), dst=dst)
-    return frame
+    g = FrameGatherer(w, h, slab.dtype, slab.device, dist, dst=dst, slots=1)
+    g.submit(slab.contiguous(), 0)
+    return g.finish(0)

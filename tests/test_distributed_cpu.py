@@ -74,3 +74,53 @@ def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, case
     assert np.array_equal(np.load(out + ".f32.npy"), ref["f32"])
     co = g["coords"]
     assert np.array_equal(ref["u8"][:, co[:, 0], co[:, 1]].T, g["u8"])
+
+
+def _pipe_worker(rank, world, port, out_path):
+    """Double-buffered FrameGatherer over several different frames, as bench.py drives it."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from python_ray_tracer_amd.distributed import slab_bounds, FrameGatherer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = load_frame("c1_128")
+    w, h = 128, 128
+    x0, x1 = slab_bounds(w, world, rank)
+    gat = FrameGatherer(w, h, torch.uint8, torch.device("cpu"), dist, dst=0, slots=2)
+    assert gat.equal
+    slabs = [torch.zeros((3, x1 - x0, h), dtype=torch.uint8) for _ in range(2)]
+    busy, got = [None, None], {}
+    for i in range(5):
+        b = i % 2
+        if busy[b] is not None:
+            f = gat.finish(b)
+            if rank == 0:
+                got[busy[b]] = f.numpy().copy()
+        r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
+                       raygen=raygen_closed_form(w, h, 45.0), x0=x0, x1=x1, want=("u8",), nthreads=2)
+        slabs[b].copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
+        gat.submit(slabs[b], b)
+        busy[b] = i
+    for b in range(2):
+        if busy[b] is not None:
+            f = gat.finish(b)
+            if rank == 0:
+                got[busy[b]] = f.numpy().copy()
+    if rank == 0:
+        np.savez(out_path, **{f"f{i}": v for i, v in got.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gatherer_keeps_frames_apart(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frames.npz")
+    mp.spawn(_pipe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    g = load_frame("c1_128")
+    for i in range(5):
+        ref = oracle.render(128, 128, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
+                            raygen=raygen_closed_form(128, 128, 45.0), want=("u8",))["u8"]
+        assert np.array_equal(got[f"f{i}"], ref), f"frame {i}"
