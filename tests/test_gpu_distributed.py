@@ -1,0 +1,68 @@
+"""RCCL-side checks that fit a one-GPU box: the FrameGatherer call pattern (async gather into views of a
+staging buffer, strided assembly copy, double-buffering) on the `nccl` backend with world_size 1, fed by
+the HIP kernel on the stream torch considers current.  Multi-rank assembly is covered on CPU (gloo)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r"""
+import os, sys, hashlib
+sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import python_ray_tracer_amd as pkg
+from python_ray_tracer_amd import workloads
+from python_ray_tracer_amd.distributed import FrameGatherer, slab_bounds
+from conftest import load_frame
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+wl = workloads.build("c1_128x128_s3_d1"); cam = wl["camera"]; w, h = wl["w"], wl["h"]
+r = pkg.Renderer(0)
+r.set_scene(wl["spheres"], wl["lights"], wl["planes"]); r.set_camera(cam.position, cam.rotation); r.set_raygen(w, h, *cam.raygen())
+s = torch.cuda.Stream(device=dev); torch.cuda.set_stream(s)
+g = FrameGatherer(w, h, torch.uint8, dev, dist, dst=0, slots=2)
+slabs = [torch.zeros((3, w, h), dtype=torch.uint8, device=dev) for _ in range(2)]
+frames = {}
+busy = [None, None]
+for i in range(4):
+    b = i %% 2
+    if busy[b] is not None:
+        frames[busy[b]] = g.finish(b).cpu().numpy().copy()
+    p = r.params(wl["amb"], wl["lamb"], wl["refl"], i %% 2, False)      # depth alternates 0/1
+    r.render_device(p, 0, w, slabs[b].data_ptr(), None, w * h, s.cuda_stream)
+    g.submit(slabs[b], b); busy[b] = i
+for b in range(2):
+    frames[busy[b]] = g.finish(b).cpu().numpy().copy()
+torch.cuda.synchronize()
+gold = load_frame("c1_128")["frame_u8"]
+assert np.array_equal(frames[1], gold) and np.array_equal(frames[3], gold), "depth-1 frames differ from the golden frame"
+assert np.array_equal(frames[0], frames[2]) and not np.array_equal(frames[0], frames[1])
+r.close(); dist.destroy_process_group()
+print("NCCL_GATHER_OK")
+"""
+
+
+def test_frame_gatherer_on_nccl_world1():
+    out = subprocess.run([sys.executable, "-c", SCRIPT % {"repo": REPO}], capture_output=True, text=True, timeout=600)
+    assert "NCCL_GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_runs_under_torchrun_world1():
+    """bench.py through the launcher the driver uses for N>1 (here N=1): one JSON line, frame hash ok."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29544", os.path.join(REPO, "bench.py"),
+                          "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["frame_matches_reference_sha256"] is True and j["roofline"]["frac"] > 0
