@@ -111,13 +111,23 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.anchors = (table <= (size_t)rt::MAX_CULL_TABLE_BYTES) ? ctx->L + 1 : 0;
     const double cam2 = ctx->cam_o[0] * ctx->cam_o[0] + ctx->cam_o[1] * ctx->cam_o[1] + ctx->cam_o[2] * ctx->cam_o[2];
     k.extent2 = (float)(1.0001 * (cam2 > ctx->scene_extent2 ? cam2 : ctx->scene_extent2));
-    const size_t lds = rt::lds_bytes(ctx->S, ctx->P, ctx->L, k.anchors);
+    // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 6 workgroups per CU still
+    // fit their LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
+    const bool aa = k.aa != 0;
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, k.anchors, aa, true);
+    const bool park = lds_park * 6 <= 160 * 1024;
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, k.anchors, aa, false);
+    const void *fn = aa ? (park ? (const void *)rt::render_kernel<true, true> : (const void *)rt::render_kernel<true, false>)
+                        : (park ? (const void *)rt::render_kernel<false, true> : (const void *)rt::render_kernel<false, false>);
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
-        RT_HIP(ctx, hipFuncSetAttribute((const void *)rt::render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (const void *f : {(const void *)rt::render_kernel<true, true>, (const void *)rt::render_kernel<true, false>,
+                              (const void *)rt::render_kernel<false, true>, (const void *)rt::render_kernel<false, false>})
+            RT_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
     }
     const unsigned grid = (unsigned)((k.ntiles + rt::WAVES_PER_WG - 1) / rt::WAVES_PER_WG);
-    hipLaunchKernelGGL(rt::render_kernel, dim3(grid), dim3(rt::WG_THREADS), lds, stream, k);
+    void *args[] = {(void *)&k};
+    RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(rt::WG_THREADS), args, lds, stream));
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -374,7 +384,7 @@ int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info)
     if (!info) return fail(ctx, RT_ERR_BAD_ARG, "info is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipFuncAttributes a;
-    RT_HIP(ctx, hipFuncGetAttributes(&a, (const void *)rt::render_kernel));
+    RT_HIP(ctx, hipFuncGetAttributes(&a, (const void *)rt::render_kernel<false, true>));
     hipDeviceProp_t prop;
     RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     std::memset(info, 0, sizeof *info);

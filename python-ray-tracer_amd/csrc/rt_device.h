@@ -31,9 +31,6 @@
 #ifndef RT_PREFILTER
 #define RT_PREFILTER 1
 #endif
-#ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 6   // 80 VGPRs: 6 waves/SIMD measured faster than 5 (96) or 4 (105) despite a few spills
-#endif
 #ifndef RT_ABLATE
 #define RT_ABLATE 0   // diagnostic builds only: 1 = no shadow queries, 2 = cheap shading normalise, 3 = no sphere loop in closest hit
 #endif
@@ -48,6 +45,10 @@ constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, 
 constexpr int LT_STRIDE = 4;       // x,y,z,pad
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, w+margin (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
+#ifndef RT_CULL_UNROLL
+#define RT_CULL_UNROLL 4
+#endif
+constexpr int CULL_UNROLL = RT_CULL_UNROLL;   // spheres culled per straight-line group (ILP vs registers)
 
 struct KParams {
     const double *scene;       // packed records: S spheres, then P planes, then L lights
@@ -121,6 +122,29 @@ __device__ __forceinline__ V3 renormalize_unit(const V3 &d)
 
 enum { HIT_NONE = 0, HIT_SPHERE = 1, HIT_PLANE = 2 };
 
+// A per-lane V3 that lives either in LDS (PARK: slot `slot` of the per-thread area, [component][thread] so
+// consecutive lanes hit consecutive banks) or in registers.  Parking long-lived values (the running colour,
+// the incoming direction during the light loop, the AA tap sums) is what takes the kernel from 5 to 7
+// waves/SIMD; the compiler would otherwise spill them to scratch, i.e. to HBM.  volatile + explicit LDS
+// address space: a real ds_read/ds_write round trip through ONE 32-bit address (without volatile the stores
+// are forwarded and the values stay in VGPRs; without the address space the accesses become flat).
+// Scenes whose LDS image is too large for 6+ workgroups per CU run the register variant (host picks).
+typedef __attribute__((address_space(3))) double lds_f64;
+template <bool PARK> struct Park3 {
+    volatile lds_f64 *p;
+    V3 v;
+    __device__ __forceinline__ Park3(double *base, int slot)
+        : p((volatile lds_f64 *)base + slot * 3 * WG_THREADS + threadIdx.x), v{0.0, 0.0, 0.0} {}
+    __device__ __forceinline__ void set(const V3 &a)
+    {
+        if constexpr (PARK) { p[0] = a.x; p[WG_THREADS] = a.y; p[2 * WG_THREADS] = a.z; } else v = a;
+    }
+    __device__ __forceinline__ V3 get() const
+    {
+        if constexpr (PARK) return V3{p[0], p[WG_THREADS], p[2 * WG_THREADS]}; else return v;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Conservative float32 cull.  For a ray (o, R) and sphere (c, r2) the reference computes, in
 // float64, D = s² - a·(|L|² - r2) with L = o - c, s = L·R, and reports a miss when D < 0, or when
@@ -153,6 +177,10 @@ struct Lds {
     const double *rec;     // float64 records
     const float *sph32;    // S x {cx,cy,cz,r2}
     const float *tab;      // anchors x S x CULL_STRIDE
+    double *acc;           // 6 (9 with AA) x WG_THREADS doubles, [slot][thread] (consecutive lanes -> consecutive banks):
+                           // slots 0-2 the running colour of the current sample, 3-5 the incoming direction
+                           // during the light loop, 6-8 (AA kernel only) the tap sums — kept out of VGPRs that would stay
+                           // live across every query of every bounce (registers decide occupancy here)
 };
 
 struct RayF {              // float32 shadow of a query, for the cull only
@@ -205,9 +233,9 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
     // manual 4-way unroll: indices past the chunk are clamped (they recompute the last sphere's bit)
     if (anchor >= 0) {
         const float *tab = lds.tab + ((size_t)anchor * S + k0) * CULL_STRIDE;
-        for (int j = 0; j < n; j += 4) {
+        for (int j = 0; j < n; j += CULL_UNROLL) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CULL_UNROLL; ++u) {
                 const int jj = (j + u < n) ? j + u : n - 1;
                 const bool culled = cull_anchored(tab + jj * CULL_STRIDE, q) || (self_culled && (k0 + jj) == self);
                 mask |= (__ballot(!culled) != 0ull ? 1ull : 0ull) << jj;
@@ -215,9 +243,9 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
         }
     } else {
         const float *sp = lds.sph32 + 4 * k0;
-        for (int j = 0; j < n; j += 4) {
+        for (int j = 0; j < n; j += CULL_UNROLL) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CULL_UNROLL; ++u) {
                 const int jj = (j + u < n) ? j + u : n - 1;
                 const bool culled = cull_origin(sp + 4 * jj, q);
                 mask |= (__ballot(!culled) != 0ull ? 1ull : 0ull) << jj;
@@ -247,7 +275,6 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     const V3 R = renormalize_unit(d);                         // == normalize(d), intersections.py:13
     const double a = dot3(R, R);
 #if RT_PREFILTER
-    const RayF qf = make_rayf(o, R, p.extent2);
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
     double bestn = __builtin_inf();
@@ -255,7 +282,11 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     for (int k0 = 0; k0 < (RT_ABLATE == 3 ? 0 : S); k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
-      unsigned long long mask = cull_mask(lds, S, canchor, k0, n, qf, -1, false);
+      unsigned long long mask;
+      {   // the float32 ray is rebuilt per chunk (10 ops) so that it is not live during the float64 phase
+          const RayF qf = make_rayf(o, R, p.extent2);
+          mask = cull_mask(lds, S, canchor, k0, n, qf, -1, false);
+      }
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
@@ -307,16 +338,18 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
     const bool a_sane = (a > 0.999999 && a < 1.000001);
     bool occ = false;
 #if RT_PREFILTER
-    const RayF qf = make_rayf(o, R, p.extent2);
     const int canchor = (p.anchors > 0) ? anchor : -1;
-    bool self_culled = false;
-    if (canchor >= 0 && self >= 0) self_culled = cull_origin(lds.sph32 + 4 * self, qf);
 #endif
     for (int k0 = 0; k0 < S; k0 += 64) {
       if (__ballot(!occ) == 0ull) break;
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
-      unsigned long long mask = cull_mask(lds, S, canchor, k0, n, qf, self, self_culled);
+      unsigned long long mask;
+      {
+          const RayF qf = make_rayf(o, R, p.extent2);
+          const bool self_culled = (canchor >= 0 && self >= k0 && self < k0 + n) ? cull_origin(lds.sph32 + 4 * self, qf) : false;
+          mask = cull_mask(lds, S, canchor, k0, n, qf, self, self_culled);
+      }
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
@@ -375,6 +408,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
 
 // trace.py:44-112.  On entry `alive` lanes carry a ray (o,d); on exit `alive` is false for lanes
 // that missed (the reference's 404 sentinels), rgb is this bounce's colour, (o,d) the next ray.
+template <bool PARK>
 __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                              V3 &o, V3 &d, V3 &rgb)
 {
@@ -385,21 +419,29 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     alive = alive && (type != HIT_NONE);                                      // :56-57
     if (alive) {
         V3 Pt{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                   // :60 (1.0*o is exact)
-        V3 col, N, bN;
+        // PARK: the object's colour is re-read from its LDS record where it is used (volatile: at the point of
+        // use) instead of being held in 6 VGPRs across the shadow queries
+        const int coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : S * SPH_STRIDE + idx * PL_STRIDE + 12;
+        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.rec + coff;
+        V3 colr{0.0, 0.0, 0.0};
+        if constexpr (!PARK) colr = V3{lds.rec[coff], lds.rec[coff + 1], lds.rec[coff + 2]};
+        auto col = [&](int c) -> double { if constexpr (PARK) return colp[c]; else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z); };
+        V3 N, bN;
         if (type == HIT_SPHERE) {                                             // :63-66
             const double *g = lds.rec + idx * SPH_STRIDE;
-            col = V3{g[4], g[5], g[6]};
             N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});        // common.py:94-101
             bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
         } else {                                                              // :68-71
             const double *g = lds.rec + S * SPH_STRIDE + idx * PL_STRIDE;
             N = V3{g[6], g[7], g[8]};                                         // float32-renormalised, host-side
             bN = V3{g[9], g[10], g[11]};                                      // BIAS*N as the reference rounds it
-            col = V3{g[12], g[13], g[14]};
         }
-        rgb = V3{p.amb * col.x, p.amb * col.y, p.amb * col.z};                // :77 (0 + amb*col)
+        rgb = V3{p.amb * col(0), p.amb * col(1), p.amb * col(2)};             // :77 (0 + amb*col)
         Pt = V3{Pt.x + bN.x, Pt.y + bN.y, Pt.z + bN.z};                       // :82-83
         const int self = (type == HIT_SPHERE) ? idx : -1;
+        Park3<PARK> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
+        dpark.set(d);
+
         const double *lt = lds.rec + S * SPH_STRIDE + P * PL_STRIDE;
         for (int m = 0; m < L; ++m) {                                         // :86-102
             const double *g = lt + m * LT_STRIDE;
@@ -413,9 +455,10 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 #else
                 const bool occluded = any_hit(lds, p, Pt, Ld, 1 + m, self);
 #endif
-                if (!occluded) rgb = V3{rgb.x + k * col.x, rgb.y + k * col.y, rgb.z + k * col.z};
+                if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
+        d = dpark.get();
         const double c2 = -2.0 * dot3(d, N);                                  // common.py:113-120
         // |d - 2(d.N)N| = 1 up to rounding for unit d, N: the exact unit-vector path applies (it falls
         // back to sqrt-and-divide by itself otherwise)
@@ -426,20 +469,23 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 }
 
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
+template <bool PARK>
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d)
 {
-    V3 acc{0.0, 0.0, 0.0};
+    Park3<PARK> acc(lds.acc, 0);                                              // the running colour
+    acc.set(V3{0.0, 0.0, 0.0});
     for (int b = 0; b <= p.depth; ++b) {
         if (__ballot(alive) == 0ull) break;                                   // wave-uniform exit
         V3 rgb;
-        trace_bounce(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
-        if (b == 0) acc = rgb;                                                // :120
+        trace_bounce<PARK>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
+        if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
             const double wgt = p.refl_pow[b - 1];
-            acc = V3{acc.x + wgt * rgb.x, acc.y + wgt * rgb.y, acc.z + wgt * rgb.z};
+            const V3 a = acc.get();
+            acc.set(V3{a.x + wgt * rgb.x, a.y + wgt * rgb.y, a.z + wgt * rgb.z});
         }
     }
-    return acc;
+    return acc.get();
 }
 
 __device__ __forceinline__ V3 pixel_P(const KParams &p, int x, int y)
@@ -469,18 +515,24 @@ __device__ __forceinline__ uint8_t clip_color(double c)
     return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
 }
 
-// LDS image: [float64 records][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
+// LDS image: [float64 records][per-thread slots 6|9 x 256 doubles][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors)
+__host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors, bool aa, bool park)
 {
-    return lds_doubles(S, P, L) * sizeof(double) + (size_t)S * 4 * sizeof(float) + (size_t)anchors * S * CULL_STRIDE * sizeof(float);
+    return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) + (size_t)S * 4 * sizeof(float) +
+           (size_t)anchors * S * CULL_STRIDE * sizeof(float);
 }
 
-__global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(const KParams p)
+// AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
+// live state (registers decide occupancy here).
+template <bool AA, bool PARK>
+__global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? 5 : 4) : (PARK ? 7 : 5))) void render_kernel(const KParams p)
 {
     extern __shared__ double lds_raw[];
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
-    float *sph32 = reinterpret_cast<float *>(lds_raw + nrec);
+    double *accum = lds_raw + nrec;
+    float *sph32 = reinterpret_cast<float *>(accum + lds_slots(AA, PARK) * WG_THREADS);
     float *tab = sph32 + 4 * p.S;
     {   // stage the packed scene once per workgroup
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
@@ -508,7 +560,7 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(const 
     }
     __syncthreads();
 #endif
-    const Lds lds{lds_raw, sph32, tab};
+    const Lds lds{lds_raw, sph32, tab, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * WAVES_PER_WG + wave;
@@ -520,26 +572,36 @@ __global__ __launch_bounds__(WG_THREADS, RT_MIN_WAVES) void render_kernel(const 
     const int xc = inb ? x : p.x0, yc = inb ? y : 0;                          // keep addresses valid for idle lanes
 
     const V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]};                           // kernels.py:16
-    const V3 Pp = pixel_P(p, xc, yc);
-    V3 c = sample(lds, p, inb, o, primary_dir(p, Pp));                        // kernels.py:26
-    double R = c.x, G = c.y, B = c.z;
-
-    if (p.aa) {                                                               // kernels.py:29-65
+    double R, G, B;
+    if constexpr (!AA) {
+        const V3 c = sample<PARK>(lds, p, inb, o, primary_dir(p, pixel_P(p, xc, yc)));   // kernels.py:19-26
+        R = c.x; G = c.y; B = c.z;
+    } else {
+        // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
+        // if some lane of the wave is interior).  One inlined copy of sample(); the tap sums live in LDS
+        // (slots 3-5), not in VGPRs that would stay live across every query.
         const bool interior = inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
-        if (__ballot(interior) != 0ull) {
-            // neighbour offsets (dx,dy)+1 packed 2 bits each, in the order of kernels.py:53:
-            // left, right, top(y+1), bottom(y-1), top-left, top-right, bottom-left, bottom-right
-            constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;
+        const int ntaps = (__ballot(interior) != 0ull) ? 9 : 1;
+        // neighbour offsets (dx,dy)+1 packed 2 bits each, in the order of kernels.py:53:
+        // left, right, top(y+1), bottom(y-1), top-left, top-right, bottom-left, bottom-right
+        constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;
+        Park3<PARK> taps(lds.acc, 2);
 #pragma unroll 1
-            for (int k = 0; k < 8; ++k) {
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const V3 Pp = pixel_P(p, xc, yc);                                 // :19
+            V3 Pt = Pp;
+            if (tap) {
+                const int k = tap - 1;
                 const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
                 const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
-                const V3 Pt{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
-                const V3 s = sample(lds, p, interior, o, primary_dir(p, Pt));
-                if (interior) { R += s.x; G += s.z; B += s.y; }               // :58-60 (G += B_s; B += G_s)
+                Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
             }
-            if (interior) { R = R / 9; G = G / 9; B = B / 9; }                // :63-65
+            const V3 s = sample<PARK>(lds, p, tap ? interior : inb, o, primary_dir(p, Pt));   // :26 / :56
+            if (tap == 0) taps.set(s);
+            else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.z, a.z + s.y}); }   // :58-60 (G += B_s; B += G_s)
         }
+        { const V3 a = taps.get(); R = a.x; G = a.y; B = a.z; }
+        if (interior) { R = R / 9; G = G / 9; B = B / 9; }                    // :63-65
     }
 
     if (inb) {
