@@ -18,3 +18,8 @@ def _build(name, tmp_path):
 def test_renormalize_unit_is_bit_identical_to_sqrt_and_divide(tmp_path):
     out = subprocess.check_output([_build("renorm_check", tmp_path), "3000000"], text=True)
     assert "mismatches=0" in out and "fast_path=3000000" in out, out
+
+
+def test_shared_reciprocal_normalize_is_bit_identical(tmp_path):
+    out = subprocess.check_output([_build("normalize_check", tmp_path), "5000000"], text=True)
+    assert "mismatches=0" in out and "sqrt_mismatches=0" in out, out
