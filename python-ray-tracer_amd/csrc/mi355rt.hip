@@ -107,7 +107,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     std::memcpy(k.refl_pow, p->refl_pow, sizeof k.refl_pow);
 
     // anchored cull table (camera + one anchor per light) if it fits its LDS budget, else origin-form culling only
-    const size_t table = (size_t)(ctx->L + 1) * ctx->S * rt::CULL_STRIDE * sizeof(float);
+    const size_t table = (size_t)(ctx->L + 1) * rt::pad4(ctx->S) * rt::CULL_STRIDE * sizeof(float);
     k.anchors = (table <= (size_t)rt::MAX_CULL_TABLE_BYTES) ? ctx->L + 1 : 0;
     const double cam2 = ctx->cam_o[0] * ctx->cam_o[0] + ctx->cam_o[1] * ctx->cam_o[1] + ctx->cam_o[2] * ctx->cam_o[2];
     k.extent2 = (float)(1.0001 * (cam2 > ctx->scene_extent2 ? cam2 : ctx->scene_extent2));

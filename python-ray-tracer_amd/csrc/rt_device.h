@@ -269,29 +269,35 @@ __device__ __forceinline__ bool cull_origin(const float *__restrict__ c, const R
     return (D < -mg) || (s > es && cc > mg);
 }
 
+// 1 if the (wave-uniform) ballot word is non-zero
+__device__ __forceinline__ unsigned long long nz64(unsigned long long b) { return (b | (0ull - b)) >> 63; }
+__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+
+// Both float32 tables are padded to a multiple of 4 spheres with entries that always certify a miss
+// (w = -inf), so the 4-way unrolled groups below need no bounds handling and use immediate LDS offsets
+// (the compiler packs the four independent chains into v_pk_mul/fma_f32, two spheres per instruction).
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
                                                         const RayF &q, int self, bool self_culled)
 {
     unsigned long long mask = 0ull;
-    // manual 4-way unroll: indices past the chunk are clamped (they recompute the last sphere's bit)
+    const int Sp = pad4(S), npad = pad4(n);
+    const int selfj = self_culled ? self - k0 : -1;                           // per lane
     if (anchor >= 0) {
-        const float *tab = lds.tab + ((size_t)anchor * S + k0) * CULL_STRIDE;
-        for (int j = 0; j < n; j += CULL_UNROLL) {
+        const float *tab = lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE;
+        for (int j = 0; j < npad; j += CULL_UNROLL) {
 #pragma unroll
             for (int u = 0; u < CULL_UNROLL; ++u) {
-                const int jj = (j + u < n) ? j + u : n - 1;
-                const bool culled = cull_anchored(tab + jj * CULL_STRIDE, q) || (self_culled && (k0 + jj) == self);
-                mask |= (__ballot(!culled) != 0ull ? 1ull : 0ull) << jj;
+                const bool culled = cull_anchored(tab + (j + u) * CULL_STRIDE, q) || (j + u == selfj);
+                mask |= nz64(__ballot(!culled)) << (j + u);
             }
         }
     } else {
         const float *sp = lds.sph32 + 4 * k0;
-        for (int j = 0; j < n; j += CULL_UNROLL) {
+        for (int j = 0; j < npad; j += CULL_UNROLL) {
 #pragma unroll
             for (int u = 0; u < CULL_UNROLL; ++u) {
-                const int jj = (j + u < n) ? j + u : n - 1;
-                const bool culled = cull_origin(sp + 4 * jj, q);
-                mask |= (__ballot(!culled) != 0ull ? 1ull : 0ull) << jj;
+                const bool culled = cull_origin(sp + 4 * (j + u), q);
+                mask |= nz64(__ballot(!culled)) << (j + u);
             }
         }
     }
@@ -563,8 +569,8 @@ __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (siz
 __host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }
 __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors, bool aa, bool park)
 {
-    return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) + (size_t)S * 4 * sizeof(float) +
-           (size_t)anchors * S * CULL_STRIDE * sizeof(float);
+    return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) + (size_t)pad4(S) * 4 * sizeof(float) +
+           (size_t)anchors * pad4(S) * CULL_STRIDE * sizeof(float);
 }
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
@@ -576,27 +582,32 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? 5 : 4) : (PARK ? 7 : 5)))
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     double *accum = lds_raw + nrec;
     float *sph32 = reinterpret_cast<float *>(accum + lds_slots(AA, PARK) * WG_THREADS);
-    float *tab = sph32 + 4 * p.S;
+    const int Sp = pad4(p.S);
+    float *tab = sph32 + 4 * Sp;
     {   // stage the packed scene once per workgroup
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
     }
     __syncthreads();
 #if RT_PREFILTER
     {   // float32 sphere table (exact: the scene is float32) and the anchored cull table
-        for (int k = threadIdx.x; k < p.S; k += WG_THREADS) {
+        const float NINF = -__builtin_inff();
+        for (int k = threadIdx.x; k < Sp; k += WG_THREADS) {
             const double *g = lds_raw + k * SPH_STRIDE;
-            sph32[4 * k + 0] = (float)g[0]; sph32[4 * k + 1] = (float)g[1]; sph32[4 * k + 2] = (float)g[2]; sph32[4 * k + 3] = (float)g[3];
+            const bool real = k < p.S;
+            sph32[4 * k + 0] = real ? (float)g[0] : 0.0f; sph32[4 * k + 1] = real ? (float)g[1] : 0.0f;
+            sph32[4 * k + 2] = real ? (float)g[2] : 0.0f; sph32[4 * k + 3] = real ? (float)g[3] : NINF;
         }
         const double *lt = lds_raw + p.S * SPH_STRIDE + p.P * PL_STRIDE;
-        for (int e = threadIdx.x; e < p.anchors * p.S; e += WG_THREADS) {
-            const int a = e / p.S, k = e - a * p.S;
+        for (int e = threadIdx.x; e < p.anchors * Sp; e += WG_THREADS) {
+            const int a = e / Sp, k = e - a * Sp;
+            float *t = tab + (size_t)e * CULL_STRIDE;
+            if (k >= p.S) { t[0] = t[1] = t[2] = 0.0f; t[3] = NINF; continue; }   // padding: always culled
             const double *g = lds_raw + k * SPH_STRIDE;
             const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
             const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
             const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
             const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
             const double ll = lx * lx + ly * ly + lz * lz;
-            float *t = tab + (size_t)e * CULL_STRIDE;
             t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
             t[3] = (float)((g[3] - ll) + (ll + g[3]) * (double)CULL_K_ANCHOR);     // w + margin
         }
