@@ -564,12 +564,14 @@ __device__ __forceinline__ uint8_t clip_color(double c)
     return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
 }
 
-// LDS image: [float64 records][per-thread slots 6|9 x 256 doubles][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
+// LDS image: [float64 records][per-thread slots 6|9 x 256 doubles][256 int32 pixel offsets][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
-__host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }
+__host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x WG_THREADS doubles
+__host__ __device__ inline int lds_offset_words(bool park) { return park ? WG_THREADS : 0; }    // + one int32 per thread: the pixel offset
 __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors, bool aa, bool park)
 {
-    return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) + (size_t)pad4(S) * 4 * sizeof(float) +
+    return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) +
+           ((size_t)lds_offset_words(park) + (size_t)pad4(S) * 4) * sizeof(float) +
            (size_t)anchors * pad4(S) * CULL_STRIDE * sizeof(float);
 }
 
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? 5 : 4) : (PARK ? 7 : 5)))
     extern __shared__ double lds_raw[];
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     double *accum = lds_raw + nrec;
-    float *sph32 = reinterpret_cast<float *>(accum + lds_slots(AA, PARK) * WG_THREADS);
+    int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK) * WG_THREADS);
+    float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK));
     const int Sp = pad4(p.S);
     float *tab = sph32 + 4 * Sp;
     {   // stage the packed scene once per workgroup
@@ -624,6 +627,11 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? 5 : 4) : (PARK ? 7 : 5)))
     const int y = ty * TILE + (lane & 7);
     const bool inb = (x < p.x1) && (y < p.h);
     const int xc = inb ? x : p.x0, yc = inb ? y : 0;                          // keep addresses valid for idle lanes
+    // PARK: the pixel's output offset waits in LDS instead of staying live (or being spilled to scratch)
+    // across the whole trace; -1 marks lanes outside the frame.
+    typedef __attribute__((address_space(3))) int lds_i32;
+    volatile lds_i32 *offp = (volatile lds_i32 *)offw + threadIdx.x;
+    if constexpr (PARK) *offp = inb ? (x - p.x0) * p.h + y : -1;              // w*h <= 2^31 (checked by the host)
 
     const V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]};                           // kernels.py:16
     double R, G, B;
@@ -658,8 +666,9 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? 5 : 4) : (PARK ? 7 : 5)))
         if (interior) { R = R / 9; G = G / 9; B = B / 9; }                    // :63-65
     }
 
-    if (inb) {
-        const long long off = (long long)(x - p.x0) * p.h + y;
+    long long off;
+    if constexpr (PARK) off = *offp; else off = inb ? (long long)(x - p.x0) * p.h + y : -1ll;   // (int32 -1 sign-extends)
+    if (off >= 0) {
         if (p.out_u8) {                                                       // kernels.py:69-73, common.py:60-63
             const uint8_t r8 = clip_color(R), g8 = clip_color(G), b8 = clip_color(B);
             p.out_u8[off] = r8;
