@@ -269,8 +269,15 @@ __device__ __forceinline__ bool cull_origin(const float *__restrict__ c, const R
     return (D < -mg) || (s > es && cc > mg);
 }
 
-// 1 if the (wave-uniform) ballot word is non-zero
-__device__ __forceinline__ unsigned long long nz64(unsigned long long b) { return (b | (0ull - b)) >> 63; }
+// 1 if some live lane's predicate holds — decided and kept on the scalar unit (a C expression on the ballot
+// word is lowered through v_cndmask + v_readfirstlane)
+__device__ __forceinline__ unsigned long long any_lane(bool pred)
+{
+    const unsigned long long b = __ballot(pred);
+    unsigned r;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(b) : "scc");
+    return r;
+}
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
 // Both float32 tables are padded to a multiple of 4 spheres with entries that always certify a miss
@@ -288,7 +295,7 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
 #pragma unroll
             for (int u = 0; u < CULL_UNROLL; ++u) {
                 const bool culled = cull_anchored(tab + (j + u) * CULL_STRIDE, q) || (j + u == selfj);
-                mask |= nz64(__ballot(!culled)) << (j + u);
+                mask |= any_lane(!culled) << (j + u);
             }
         }
     } else {
@@ -297,7 +304,7 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
 #pragma unroll
             for (int u = 0; u < CULL_UNROLL; ++u) {
                 const bool culled = cull_origin(sp + 4 * (j + u), q);
-                mask |= nz64(__ballot(!culled)) << (j + u);
+                mask |= any_lane(!culled) << (j + u);
             }
         }
     }
@@ -578,7 +585,13 @@ __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors, bo
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
 template <bool AA, bool PARK>
-__global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? 5 : 4) : (PARK ? 7 : 5))) void render_kernel(const KParams p)
+#ifndef RT_W_PARK
+#define RT_W_PARK 7
+#endif
+#ifndef RT_W_AAPARK
+#define RT_W_AAPARK 5
+#endif
+__global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     extern __shared__ double lds_raw[];
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
