@@ -35,7 +35,7 @@ def cpu_baseline(wl, rays_per_frame, min_wall_s=2.5):
     while True:
         orc.render(wl["w"], wl["h"], cam.position, cam.rotation, wl["spheres"], wl["lights"], wl["planes"],
                    wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], raygen=cam.raygen(), want=("u8",),
-                   nthreads=threads)
+                   nthreads=threads, spp=wl["spp"], seed=wl["seed"])
         frames += 1
         dt = time.perf_counter() - t0
         if dt >= min_wall_s:
@@ -82,7 +82,7 @@ def main():
     r.set_scene(wl["spheres"], wl["lights"], wl["planes"])
     r.set_camera(cam.position, cam.rotation)
     r.set_raygen(w, h, *cam.raygen())
-    params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"])
+    params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"])
     x0, x1 = slab_bounds(w, world, rank)
     ws = x1 - x0
     # The kernel is launched on a torch-owned, non-default stream that is also torch's current stream, so
@@ -154,7 +154,7 @@ def main():
         if rays is None:   # ray counts of non-headline configs come from the oracle's counters
             from oracle import oracle as orc
             c = orc.render(w, h, cam.position, cam.rotation, wl["spheres"], wl["lights"], wl["planes"], wl["amb"], wl["lamb"],
-                           wl["refl"], wl["depth"], wl["aa"], raygen=cam.raygen(), want=())["counters"]
+                           wl["refl"], wl["depth"], wl["aa"], raygen=cam.raygen(), want=(), spp=wl["spp"], seed=wl["seed"])["counters"]
             rays = dict(closest=c["closest"], shadow=c["shadow"])
         rays_per_frame = rays["closest"] + rays["shadow"]
         ms_per_step = dt / a.steps * 1e3

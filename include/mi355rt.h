@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 #define RT_MAX_DEPTH 16      /* entries of rt_params.refl_pow (reflection bounces) */
 #define RT_MAX_SPHERES 1024  /* scene limits: the packed scene must fit one workgroup's LDS */
 #define RT_MAX_PLANES 64
@@ -49,6 +49,12 @@ typedef enum rt_status {
 #define RT_AA_REFERENCE 1 /* aliasing=True: the reference's 3x3 half-pixel taps incl. its G/B
                              accumulation order (kernels.py:29-65) on 1<=x<=w-2, 1<=y<=h-2; the
                              frame border, where the reference indexes out of bounds, gets one tap */
+#define RT_AA_STOCHASTIC 2 /* build-defined (the reference has no such mode; README "anti aliasing" to-do):
+                             rt_params.spp samples per pixel at P + u*dy*y^ + v*dz*z^ with (u,v) in [-1/2,1/2)^2
+                             from a counter hash of (x, y, sample, seed) — rt_device.h:jitter(); plain mean of the
+                             samples' (R,G,B).  Needs the closed-form ray grid (rt_set_raygen).  Each sample is
+                             the reference's sample() (trace.py:115-133) on that direction. */
+#define RT_MAX_SPP 64
 
 /* flags */
 #define RT_FLAG_TYPED_BIAS 1 /* evaluate BIAS*N of a plane hit (trace.py:82-83) in float64 (numba
@@ -68,6 +74,8 @@ typedef struct rt_params {
     int32_t depth;   /* refl_depth, 0..RT_MAX_DEPTH */
     int32_t aa_mode; /* RT_AA_* */
     int32_t flags;   /* RT_FLAG_* */
+    int32_t spp;     /* RT_AA_STOCHASTIC: samples per pixel, 1..RT_MAX_SPP (ignored otherwise) */
+    uint32_t seed;   /* RT_AA_STOCHASTIC: hash seed */
     int32_t reserved;
 } rt_params;
 

@@ -149,6 +149,59 @@ def _run_coords(job):
     return rgb64, u8
 
 
+def _run_stochastic(job):
+    """Build-defined stochastic supersampling: the reference's sample() (trace.py:115-133) on the jittered
+    directions, averaged — every arithmetic step below is the reference's own function or a plain Python float op."""
+    (coords, camspec, spheres, lights, planes, amb, lamb, refl, depth, spp, seed) = job
+    kernels, trace, common = _W["mods"][0], _W["mods"][1], _W["mods"][2]
+    try:                                   # `python oracle/gen_golden.py` puts oracle/ itself first on sys.path
+        from oracle.oracle import jitter
+    except ImportError:
+        from oracle import jitter
+    if _W.get("camspec") != camspec:
+        w_, h_, pos_, eul_, fov_ = camspec
+        _W["cam"] = camera_arrays(_W["mods"][4], w_, h_, list(pos_), list(eul_), fov_)
+        _W["camspec"] = camspec
+    cam_o, cam_R, pixel_loc = _W["cam"]
+    w, h = pixel_loc.shape[1], pixel_loc.shape[2]
+    ar = int(w / h)
+    dy, dz = (-ar - ar) / float(w - 1), (-1 - 1) / float(h - 1)
+    o = (cam_o[0], cam_o[1], cam_o[2])
+    rows = (cam_R[0, :], cam_R[1, :], cam_R[2, :])
+    rgb64, u8 = [], []
+    for x, y in coords:
+        x, y = int(x), int(y)
+        P = pixel_loc[0:3, x, y]
+        acc = None
+        for s_ in range(spp):
+            u, v = jitter(x, y, s_, seed)
+            Ps = (P[0], P[1] + u * dy, P[2] + v * dz)
+            d = common.normalize(common.matmul(rows, Ps))
+            c = trace.sample(o, d, spheres, lights, planes, np.float64(amb), np.float64(lamb), np.float64(refl), int(depth))
+            acc = c if acc is None else (acc[0] + c[0], acc[1] + c[1], acc[2] + c[2])
+        R, G, B = acc[0] / spp, acc[1] / spp, acc[2] / spp
+        rgb64.append((float(R), float(G), float(B)))
+        u8.append(common.clip_color_vector((R, G, B)))
+    return np.array(rgb64, dtype=np.float64).reshape(-1, 3), np.array(u8, dtype=np.uint8).reshape(-1, 3)
+
+
+def stochastic_case(pool, jobs, scene_mod, name, w, h, spheres, lights, planes, position, euler, amb, lamb, refl, depth, spp, seed,
+                    coords=None, fov=45.0):
+    t0 = time.time()
+    cam_o, cam_R, _ = camera_arrays(scene_mod, 4, 4, position, euler, fov)
+    coords = np.asarray(all_coords(w, h) if coords is None else coords, dtype=np.int32).reshape(-1, 2)
+    camspec = (w, h, tuple(float(v) for v in position), tuple(float(v) for v in euler), float(fov))
+    chunks = np.array_split(coords, max(1, min(len(coords), jobs * 8)))
+    res = pool.map(_run_stochastic, [(c, camspec, spheres, lights, planes, amb, lamb, refl, depth, spp, seed) for c in chunks])
+    rgb64 = np.concatenate([r[0] for r in res]); u8 = np.concatenate([r[1] for r in res])
+    meta = dict(w=w, h=h, spheres=spheres, lights=lights, planes=planes, cam_origin=cam_o, cam_rot=cam_R,
+                position=np.array(position, dtype=np.float64), euler=np.array(euler, dtype=np.float64), fov=fov,
+                amb=amb, lamb=lamb, refl=refl, depth=depth, aa=2, spp=spp, seed=seed,
+                refl_pow=np.array([np.float64(refl) ** (i + 1) for i in range(max(depth, 1))], dtype=np.float64))
+    save_case(name, meta, coords, rgb64, u8)
+    print(f"  {name}: {time.time()-t0:.1f}s", flush=True)
+
+
 def run_case(pool, jobs, coords, camspec, spheres, lights, planes, amb, lamb, refl, depth, aa):
     coords = np.asarray(coords, dtype=np.int32).reshape(-1, 2)
     nchunk = max(1, min(len(coords), jobs * 8))
@@ -389,6 +442,13 @@ def main():
             S256 = sph(grid_scene(16, 356))
             cs = [(x, y) for x in range(48, 7680, 96) for y in range(48, 4320, 96)]
             fc("c5_s256_d8_sub96", 7680, 4320, S256, L3, P1, *CAM, 0.0, 0.6, 0.3, 8, False, coords=cs)
+        if want("stochastic"):  # build-defined stochastic supersampling; golden = the reference's sample() per jittered ray
+            sc = lambda *x, **k: stochastic_case(pool, a.jobs, scene_mod, *x, **k)  # noqa: E731
+            sc("stoch_48_spp4", 48, 48, S6, L3, P1, *CAM, 0.0, 0.6, 0.3, 2, 4, 1)
+            sc("stoch_40x24_spp3_seed7", 40, 24, S8, L3, P1, *CAM, 0.05, 0.6, 0.3, 1, 3, 7)
+            S256 = sph(grid_scene(16, 356))   # BASELINE config 5 with its 4 spp, on the same lattice as c5_s256_d8_sub96
+            cs = [(x, y) for x in range(48, 7680, 96) for y in range(48, 4320, 96)]
+            sc("c5_s256_d8_spp4_sub96", 7680, 4320, S256, L3, P1, *CAM, 0.0, 0.6, 0.3, 8, 4, 1, coords=cs)
         if want("c2"):  # BASELINE config 2, the headline frame: full reference frame
             fc("c2_1080p", 1920, 1080, S8, L3, P1, *CAM, 0.0, 0.6, 0.3, 3, False, keep_full_u8=True, f64_stride=8)
 

@@ -49,11 +49,11 @@ def lib():
         L.orc_sample.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, dp, dp, C.c_double, C.c_double, dp, C.c_int, C.c_int, dp]
         L.orc_render.argtypes = [C.POINTER(_RayGen), dp, dp, fp, C.c_int, fp, C.c_int, fp, C.c_int,
                                  C.c_double, C.c_double, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.c_uint32]
         L.orc_render.restype = C.c_int
         L.orc_render_pixels.argtypes = [C.POINTER(_RayGen), dp, dp, fp, C.c_int, fp, C.c_int, fp, C.c_int,
                                         C.c_double, C.c_double, dp, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32]
         L.orc_render_pixels.restype = C.c_int
         L.orc_max_threads.restype = C.c_int
         _lib = L
@@ -116,6 +116,25 @@ def clip_color(c):
     return lib().orc_clip_color(float(c))
 
 
+def _aa_code(aa, spp):
+    """0 none, 1 the reference's 9-tap mode, 0x100|spp stochastic supersampling (aa == 2)."""
+    if int(aa) == 2:
+        assert 1 <= int(spp) <= 64
+        return 0x100 | int(spp)
+    return int(bool(aa))
+
+
+def jitter(x, y, s, seed):
+    """(u, v) in [-1/2, 1/2)^2 of sample s of pixel (x, y): the counter hash of rt_oracle.c:jitter_hash."""
+    M = 0xFFFFFFFF
+    h = (seed ^ 0x9E3779B9) & M
+    h = ((h ^ x) * 0x85EBCA6B) & M; h ^= h >> 13
+    h = ((h ^ y) * 0xC2B2AE35) & M; h ^= h >> 16
+    h = ((h ^ s) * 0x27D4EB2F) & M; h ^= h >> 15
+    h = (h * 0x165667B1) & M; h ^= h >> 13
+    return (h & 0xFFFF) * 2.0 ** -16 + (2.0 ** -17 - 0.5), (h >> 16) * 2.0 ** -16 + (2.0 ** -17 - 0.5)
+
+
 def refl_powers(refl, depth):
     """refl ** (i+1) as the reference evaluates it (trace.py:131)."""
     return np.array([float(refl) ** (i + 1) for i in range(max(int(depth), 1))], dtype=np.float64)
@@ -130,7 +149,8 @@ def sample(spheres, lights, planes, o, d, amb, lamb, refl, depth, flags=0):
 
 
 def render(w, h, cam_origin, cam_rot, spheres, lights, planes, amb, lamb, refl, depth, aa=False, *,
-           pixel_loc=None, raygen=None, x0=0, x1=None, flags=0, want=("u8", "f64"), nthreads=0, refl_pow=None):
+           pixel_loc=None, raygen=None, x0=0, x1=None, flags=0, want=("u8", "f64"), nthreads=0, refl_pow=None,
+           spp=0, seed=1):
     """Run the restated `render` (kernels.py:6-73) for columns [x0,x1).
 
     raygen = (px, y0, dy, z0, dz) closed form, or pixel_loc = explicit float64 (3,w,h) array.
@@ -158,11 +178,11 @@ def render(w, h, cam_origin, cam_rot, spheres, lights, planes, amb, lamb, refl, 
     f32 = np.zeros((3, w, h), np.float32) if "f32" in want else None
     cnt = (C.c_longlong * 3)()
     rc = L.orc_render(C.byref(rg), _dp(o), _dp(R), _fp(spheres), spheres.shape[1], _fp(lights), lights.shape[1],
-                      _fp(planes), planes.shape[1], float(amb), float(lamb), _dp(rp), int(depth), int(bool(aa)), int(flags),
+                      _fp(planes), planes.shape[1], float(amb), float(lamb), _dp(rp), int(depth), _aa_code(aa, spp), int(flags),
                       int(x0), int(x1),
                       u8.ctypes.data if u8 is not None else None,
                       f64.ctypes.data if f64 is not None else None,
-                      f32.ctypes.data if f32 is not None else None, cnt, int(nthreads))
+                      f32.ctypes.data if f32 is not None else None, cnt, int(nthreads), int(seed) & 0xFFFFFFFF)
     if rc != 0:
         raise ValueError("orc_render: bad arguments")
     if u8 is not None: out["u8"] = u8
@@ -173,7 +193,7 @@ def render(w, h, cam_origin, cam_rot, spheres, lights, planes, amb, lamb, refl, 
 
 
 def render_pixels(w, h, coords, cam_origin, cam_rot, spheres, lights, planes, amb, lamb, refl, depth, aa=False, *,
-                  pixel_loc=None, raygen=None, flags=0, nthreads=0, refl_pow=None):
+                  pixel_loc=None, raygen=None, flags=0, nthreads=0, refl_pow=None, spp=0, seed=1):
     """The same per-pixel path for an explicit (n,2) list of (x,y) pixels.
     Returns (u8 (n,3) in stored order [R,B,G], f64 (n,3) = pre-clip (R,G,B))."""
     L = lib()
@@ -195,8 +215,8 @@ def render_pixels(w, h, coords, cam_origin, cam_rot, spheres, lights, planes, am
     u8 = np.zeros((n, 3), np.uint8)
     f64 = np.zeros((n, 3), np.float64)
     rc = L.orc_render_pixels(C.byref(rg), _dp(o), _dp(R), _fp(spheres), spheres.shape[1], _fp(lights), lights.shape[1],
-                             _fp(planes), planes.shape[1], float(amb), float(lamb), _dp(rp), int(depth), int(bool(aa)),
-                             int(flags), co.ctypes.data, n, u8.ctypes.data, f64.ctypes.data, int(nthreads))
+                             _fp(planes), planes.shape[1], float(amb), float(lamb), _dp(rp), int(depth), _aa_code(aa, spp),
+                             int(flags), co.ctypes.data, n, u8.ctypes.data, f64.ctypes.data, int(nthreads), int(seed) & 0xFFFFFFFF)
     if rc != 0:
         raise ValueError("orc_render_pixels: bad arguments")
     return u8, f64

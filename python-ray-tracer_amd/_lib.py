@@ -5,11 +5,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MI355RT_SO") or os.path.join(HERE, "libmi355rt.so")   # env override: A/B profiling of other builds
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_MAX_DEPTH = 16
 RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
-RT_AA_NONE, RT_AA_REFERENCE = 0, 1
+RT_AA_NONE, RT_AA_REFERENCE, RT_AA_STOCHASTIC = 0, 1, 2
+RT_MAX_SPP = 64
 RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB = 1, 2
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_DEVICE", -4: "RT_ERR_STATE", -5: "RT_ERR_ALLOC"}
@@ -17,7 +18,8 @@ STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_
 
 class rt_params(C.Structure):
     _fields_ = [("amb", C.c_double), ("lamb", C.c_double), ("refl_pow", C.c_double * RT_MAX_DEPTH),
-                ("depth", C.c_int32), ("aa_mode", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("depth", C.c_int32), ("aa_mode", C.c_int32), ("flags", C.c_int32), ("spp", C.c_int32),
+                ("seed", C.c_uint32), ("reserved", C.c_int32)]
 
 
 class rt_kernel_info(C.Structure):

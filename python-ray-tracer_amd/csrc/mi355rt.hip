@@ -79,7 +79,12 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     if (!ctx->have_cam) return fail(ctx, RT_ERR_STATE, "rt_set_camera has not been called");
     if (!ctx->have_grid) return fail(ctx, RT_ERR_STATE, "rt_set_raygen / rt_set_pixel_loc has not been called");
     if (p->depth < 0 || p->depth > RT_MAX_DEPTH) return fail(ctx, RT_ERR_BAD_ARG, "depth outside 0..RT_MAX_DEPTH");
-    if (p->aa_mode != RT_AA_NONE && p->aa_mode != RT_AA_REFERENCE) return fail(ctx, RT_ERR_BAD_ARG, "unknown aa_mode");
+    if (p->aa_mode != RT_AA_NONE && p->aa_mode != RT_AA_REFERENCE && p->aa_mode != RT_AA_STOCHASTIC)
+        return fail(ctx, RT_ERR_BAD_ARG, "unknown aa_mode");
+    if (p->aa_mode == RT_AA_STOCHASTIC) {
+        if (p->spp < 1 || p->spp > RT_MAX_SPP) return fail(ctx, RT_ERR_BAD_ARG, "spp outside 1..RT_MAX_SPP");
+        if (ctx->explicit_grid) return fail(ctx, RT_ERR_STATE, "RT_AA_STOCHASTIC needs the closed-form ray grid (rt_set_raygen)");
+    }
     if (x0 < 0 || x1 > ctx->w || x0 >= x1) return fail(ctx, RT_ERR_BAD_ARG, "column range must satisfy 0 <= x0 < x1 <= w");
     return RT_OK;
 }
@@ -97,6 +102,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.w = ctx->w; k.h = ctx->h; k.x0 = x0; k.x1 = x1;
     k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth;
     k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0;
+    k.spp = p->spp; k.seed = p->seed;
     k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
     const int tiles_x = (x1 - x0 + rt::TILE - 1) / rt::TILE;
     k.ntiles = tiles_x * k.tiles_y;

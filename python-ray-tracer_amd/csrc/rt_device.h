@@ -62,7 +62,8 @@ struct KParams {
     int w, h, x0, x1;
     int S, P, L, depth;
     int aa, u8_rgb, tiles_y, ntiles;
-    int anchors, pad0;         // L+1 if the anchored cull table is in use, else 0
+    int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
+    unsigned seed, pad0;       // jitter hash seed (stochastic AA)
     float extent2, pad1;       // max squared distance of camera / lights / sphere surfaces from the world origin
     double px, y0, dy, z0, dz;
     double cam_o[3];
@@ -561,6 +562,18 @@ __device__ __forceinline__ V3 primary_dir(const KParams &p, const V3 &P)
     return normalize3(v);                                                     // kernels.py:23
 }
 
+// Sub-pixel jitter of sample s of pixel (x,y) for the stochastic mode: a counter hash (no state, any launch
+// tiling gives the same frame).  u = ((h & 0xFFFF) + 1/2)/65536 - 1/2, v likewise from the high half: exact.
+__device__ __forceinline__ unsigned jitter_hash(unsigned x, unsigned y, unsigned s, unsigned seed)
+{
+    unsigned h = seed ^ 0x9E3779B9u;
+    h = (h ^ x) * 0x85EBCA6Bu; h ^= h >> 13;
+    h = (h ^ y) * 0xC2B2AE35u; h ^= h >> 16;
+    h = (h ^ s) * 0x27D4EB2Fu; h ^= h >> 15;
+    h *= 0x165667B1u; h ^= h >> 13;
+    return h;
+}
+
 // common.py:52-57: min(max(0, int(round(c))), 255), round half to even (v_rndne_f64).
 __device__ __forceinline__ uint8_t clip_color(double c)
 {
@@ -653,10 +666,11 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
         R = c.x; G = c.y; B = c.z;
     } else {
         // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
-        // if some lane of the wave is interior).  One inlined copy of sample(); the tap sums live in LDS
-        // (slots 3-5), not in VGPRs that would stay live across every query.
-        const bool interior = inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
-        const int ntaps = (__ballot(interior) != 0ull) ? 9 : 1;
+        // if some lane of the wave is interior).  One inlined copy of sample(); the tap sums live in LDS when
+        // PARK.  The same loop serves the build-defined stochastic mode (p.aa == 2): p.spp jittered samples.
+        const bool stoch = (p.aa == 2);
+        const bool interior = !stoch && inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
+        const int ntaps = stoch ? p.spp : ((__ballot(interior) != 0ull) ? 9 : 1);
         // neighbour offsets (dx,dy)+1 packed 2 bits each, in the order of kernels.py:53:
         // left, right, top(y+1), bottom(y-1), top-left, top-right, bottom-left, bottom-right
         constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;
@@ -665,18 +679,25 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
         for (int tap = 0; tap < ntaps; ++tap) {
             const V3 Pp = pixel_P(p, xc, yc);                                 // :19
             V3 Pt = Pp;
-            if (tap) {
+            if (stoch) {
+                const unsigned hh = jitter_hash((unsigned)xc, (unsigned)yc, (unsigned)tap, p.seed);
+                const double u = (double)(hh & 0xFFFFu) * 0x1p-16 + (0x1p-17 - 0.5);
+                const double v = (double)(hh >> 16) * 0x1p-16 + (0x1p-17 - 0.5);
+                Pt = V3{Pp.x, Pp.y + u * p.dy, Pp.z + v * p.dz};
+            } else if (tap) {
                 const int k = tap - 1;
                 const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
                 const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
                 Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
             }
-            const V3 s = sample<PARK>(lds, p, tap ? interior : inb, o, primary_dir(p, Pt));   // :26 / :56
+            const V3 s = sample<PARK>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt));   // :26 / :56
             if (tap == 0) taps.set(s);
+            else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.y, a.z + s.z}); }
             else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.z, a.z + s.y}); }   // :58-60 (G += B_s; B += G_s)
         }
         { const V3 a = taps.get(); R = a.x; G = a.y; B = a.z; }
-        if (interior) { R = R / 9; G = G / 9; B = B / 9; }                    // :63-65
+        if (stoch) { const double n = (double)p.spp; R = R / n; G = G / n; B = B / n; }
+        else if (interior) { R = R / 9; G = G / 9; B = B / 9; }               // :63-65
     }
 
     long long off;

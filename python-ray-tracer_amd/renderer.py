@@ -100,20 +100,23 @@ class Renderer:
             self.set_pixel_loc(pixel_loc)
 
     @staticmethod
-    def params(amb, lamb, refl, depth, aa=False, flags=0, refl_pow=None):
+    def params(amb, lamb, refl, depth, aa=False, flags=0, refl_pow=None, spp=0, seed=1):
+        """aa: False/0 none, True/1 the reference's 9-tap mode, 2 (with spp, seed) stochastic supersampling."""
         p = L.rt_params()
         p.amb, p.lamb = float(amb), float(lamb)
         rp = refl_powers(refl, depth) if refl_pow is None else np.asarray(refl_pow, dtype=np.float64)
         for i in range(min(len(rp), L.RT_MAX_DEPTH)):
             p.refl_pow[i] = float(rp[i])
-        p.depth, p.aa_mode, p.flags = int(depth), (L.RT_AA_REFERENCE if aa else L.RT_AA_NONE), int(flags)
+        p.depth, p.aa_mode, p.flags = int(depth), int(aa), int(flags)
+        p.spp, p.seed = int(spp), int(seed) & 0xFFFFFFFF
         return p
 
     # -- launches ---------------------------------------------------------------------------
-    def render(self, amb, lamb, refl, depth, aa=False, *, x0=0, x1=None, u8=True, f32=False, flags=0, refl_pow=None):
+    def render(self, amb, lamb, refl, depth, aa=False, *, x0=0, x1=None, u8=True, f32=False, flags=0, refl_pow=None,
+               spp=0, seed=1):
         """Synchronous render of columns [x0,x1) into new host arrays of shape (3, x1-x0, h)."""
         x1 = (self.w or 0) if x1 is None else int(x1)
-        p = self.params(amb, lamb, refl, depth, aa, flags, refl_pow)
+        p = self.params(amb, lamb, refl, depth, aa, flags, refl_pow, spp, seed)
         n = max(x1 - int(x0), 0)     # a bad range still goes to the library, which reports it
         out8 = np.empty((3, n, self.h or 0), np.uint8) if u8 else None
         out32 = np.empty((3, n, self.h or 0), np.float32) if f32 else None

@@ -40,7 +40,10 @@ CONFIGS = {
                            dict(closest=6309069, shadow=14017035)),
     "c4_3840x2160_s64_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(8, 355)), None),
     "c5_7680x4320_s256_d8": (7680, 4320, 8, False, lambda: _scene(grid_spheres(16, 356)), None),
+    # BASELINE config 5 proper: 4 stochastic samples per pixel (aa mode 2 = RT_AA_STOCHASTIC, seed 1)
+    "c5_7680x4320_s256_d8_spp4": (7680, 4320, 8, 2, lambda: _scene(grid_spheres(16, 356)), None),
 }
+STOCHASTIC = {"c5_7680x4320_s256_d8_spp4": dict(spp=4, seed=1)}
 HEADLINE = "c2_1920x1080_s8_d3"
 
 
@@ -49,5 +52,6 @@ def build(name):
     w, h, depth, aa, make, rays = CONFIGS[name]
     spheres, lights, planes = make().generate_scene()
     cam = Camera(resolution=(w, h), **CAMERA)
+    st = STOCHASTIC.get(name, dict(spp=0, seed=1))
     return dict(name=name, w=w, h=h, depth=depth, aa=aa, spheres=spheres, lights=lights, planes=planes,
-                camera=cam, rays=rays, **SHADER)
+                camera=cam, rays=rays, **st, **SHADER)

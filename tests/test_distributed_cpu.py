@@ -39,7 +39,7 @@ def _worker(rank, world, port, case, out_path):
     w, h = int(g["w"]), int(g["h"])
     x0, x1 = slab_bounds(w, world, rank)
     r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
-                   float(g["refl"]), int(g["depth"]), bool(g["aa"]), raygen=raygen_closed_form(w, h, float(g["fov"])),
+                   float(g["refl"]), int(g["depth"]), int(g["aa"]), raygen=raygen_closed_form(w, h, float(g["fov"])),
                    refl_pow=g["refl_pow"], x0=x0, x1=x1, want=("u8", "f32"), nthreads=2)
     for key, dt in (("u8", torch.uint8), ("f32", torch.float32)):
         slab = torch.from_numpy(np.ascontiguousarray(r[key][:, x0:x1]))
@@ -68,7 +68,7 @@ def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, case
     g = load_frame(case)
     w, h = int(g["w"]), int(g["h"])
     ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
-                        float(g["refl"]), int(g["depth"]), bool(g["aa"]), raygen=raygen_closed_form(w, h, float(g["fov"])),
+                        float(g["refl"]), int(g["depth"]), int(g["aa"]), raygen=raygen_closed_form(w, h, float(g["fov"])),
                         refl_pow=g["refl_pow"], want=("u8", "f32"))
     assert np.array_equal(np.load(out + ".u8.npy"), ref["u8"])
     assert np.array_equal(np.load(out + ".f32.npy"), ref["f32"])

@@ -30,8 +30,9 @@ def _setup(r, g, explicit_grid=False):
 
 
 def _render(r, g, **kw):
-    return r.render(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), bool(g["aa"]),
-                    u8=True, f32=True, refl_pow=g["refl_pow"], **kw)
+    return r.render(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), int(g["aa"]),
+                    u8=True, f32=True, refl_pow=g["refl_pow"], spp=int(g["spp"]) if "spp" in g else 0,
+                    seed=int(g["seed"]) if "seed" in g else 1, **kw)
 
 
 SMALL = [c for c in frame_cases() if not c.startswith(("c2_", "c4_", "c5_"))]
@@ -52,7 +53,7 @@ def test_frame_vs_golden(renderer, case):
     assert np.array_equal(f32[:, co[:, 0], co[:, 1]].T, g["rgb64"].astype(np.float32))
 
 
-@pytest.mark.parametrize("case", ["c4_s64_d5_sub32", "c5_s256_d8_sub96"])
+@pytest.mark.parametrize("case", ["c4_s64_d5_sub32", "c5_s256_d8_sub96", "c5_s256_d8_spp4_sub96"])
 def test_large_configs_sampled(renderer, case):
     """BASELINE configs 4 and 5 (1 spp) at full resolution; golden = the reference on a pixel lattice."""
     g = load_frame(case)
@@ -202,6 +203,12 @@ def test_error_behaviour(renderer):
         r.render(0.0, 0.6, 0.3, 99)          # depth > RT_MAX_DEPTH
     with pytest.raises(pkg.RenderError):
         r.render(0.0, 0.6, 0.3, 1, x0=10, x1=5)
+    with pytest.raises(pkg.RenderError):
+        r.render(0.0, 0.6, 0.3, 1, 2, spp=0)  # stochastic AA without a sample count
+    r.set_pixel_loc(np.zeros((3, 8, 8)))
+    with pytest.raises(pkg.RenderError) as e:
+        r.render(0.0, 0.6, 0.3, 1, 2, spp=4)  # stochastic AA needs the closed-form grid
+    assert e.value.status == -4
     with pytest.raises(pkg.RenderError):
         pkg.Renderer(10_000)                  # no such device
     r.close()

@@ -68,3 +68,6 @@ def test_workloads_match_golden_scenes():
             assert wl[k].tobytes() == g[k].tobytes(), (name, k)
         assert np.array_equal(wl["camera"].position, g["cam_origin"]) and np.array_equal(wl["camera"].rotation, g["cam_rot"])
         assert (wl["amb"], wl["lamb"], wl["refl"]) == (float(g["amb"]), float(g["lamb"]), float(g["refl"]))
+    wl, g = workloads.build("c5_7680x4320_s256_d8_spp4"), load_frame("c5_s256_d8_spp4_sub96")
+    assert (wl["aa"], wl["spp"], wl["seed"]) == (int(g["aa"]), int(g["spp"]), int(g["seed"]))
+    assert wl["spheres"].tobytes() == g["spheres"].tobytes()

@@ -61,8 +61,9 @@ def test_frame(oracle, case):
     g = load_frame(case)
     w, h = int(g["w"]), int(g["h"])
     u8, f64 = oracle.render_pixels(w, h, g["coords"], g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"],
-                                   float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), bool(g["aa"]),
-                                   raygen=raygen_closed_form(w, h, float(g["fov"])), refl_pow=g["refl_pow"])
+                                   float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), int(g["aa"]),
+                                   raygen=raygen_closed_form(w, h, float(g["fov"])), refl_pow=g["refl_pow"],
+                                   spp=int(g["spp"]) if "spp" in g else 0, seed=int(g["seed"]) if "seed" in g else 1)
     assert np.array_equal(u8, g["u8"])
     assert np.array_equal(f64, g["rgb64"])          # bit-exact float64
 

@@ -33,7 +33,7 @@ def main():
         r.set_scene(wl["spheres"], wl["lights"], wl["planes"]); r.set_camera(cam.position, cam.rotation); r.set_raygen(w, h, *cam.raygen())
         d8, d32 = r.malloc(3 * w * h), r.malloc(12 * w * h)
         rs.append((path, r, d8, d32))
-    p = pkg.Renderer.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], a.aa or wl["aa"])
+    p = pkg.Renderer.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 1 if a.aa else wl["aa"], spp=wl["spp"], seed=wl["seed"])
     times = {path: [] for path, *_ in rs}
     for rnd in range(a.rounds + 2):
         for path, r, d8, d32 in rs:
