@@ -6,7 +6,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <numeric>
 #include <new>
 #include <string>
 #include <vector>
@@ -30,6 +32,7 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
     int S = 0, P = 0, L = 0;
+    int NC = 0;                   // sphere clusters (0 = flat scene)
     double scene_extent2 = 0.0;   // max squared distance of lights / sphere surfaces from the world origin
     bool have_scene = false, have_cam = false, have_grid = false, explicit_grid = false;
     double cam_o[3] = {0, 0, 0}, cam_R[9] = {0};
@@ -100,7 +103,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.out_f32 = (float *)d_f32;
     k.plane_stride = plane_stride;
     k.w = ctx->w; k.h = ctx->h; k.x0 = x0; k.x1 = x1;
-    k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth;
+    k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth; k.NC = ctx->NC;
     k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0;
     k.spp = p->spp; k.seed = p->seed;
     k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
@@ -113,16 +116,16 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     std::memcpy(k.refl_pow, p->refl_pow, sizeof k.refl_pow);
 
     // anchored cull table (camera + one anchor per light) if it fits its LDS budget, else origin-form culling only
-    const size_t table = (size_t)(ctx->L + 1) * rt::pad4(ctx->S) * rt::CULL_STRIDE * sizeof(float);
+    const size_t table = (size_t)(ctx->L + 1) * (rt::padS(ctx->S, ctx->NC) + rt::pad4(ctx->NC)) * rt::CULL_STRIDE * sizeof(float);
     k.anchors = (table <= (size_t)rt::MAX_CULL_TABLE_BYTES) ? ctx->L + 1 : 0;
     const double cam2 = ctx->cam_o[0] * ctx->cam_o[0] + ctx->cam_o[1] * ctx->cam_o[1] + ctx->cam_o[2] * ctx->cam_o[2];
     k.extent2 = (float)(1.0001 * (cam2 > ctx->scene_extent2 ? cam2 : ctx->scene_extent2));
     // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 6 workgroups per CU still
     // fit their LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
     const bool aa = k.aa != 0;
-    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, k.anchors, aa, true);
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true);
     const bool park = lds_park * 6 <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, k.anchors, aa, false);
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false);
     const void *fn = aa ? (park ? (const void *)rt::render_kernel<true, true> : (const void *)rt::render_kernel<true, false>)
                         : (park ? (const void *)rt::render_kernel<false, true> : (const void *)rt::render_kernel<false, false>);
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
@@ -199,13 +202,42 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
     if (S < 0 || S > RT_MAX_SPHERES || L < 0 || L > RT_MAX_LIGHTS || P < 0 || P > RT_MAX_PLANES)
         return fail(ctx, RT_ERR_BAD_ARG, "scene size outside RT_MAX_SPHERES / RT_MAX_LIGHTS / RT_MAX_PLANES");
     if ((S && !spheres) || (L && !lights) || (P && !planes)) return fail(ctx, RT_ERR_BAD_ARG, "NULL scene array with non-zero count");
+    int nclusters = 0;
     try {
         // Packed float64 records (layout: rt_device.h).  All float32 sub-expressions of the reference
         // are evaluated here, once, in float32: r*r (intersections.py:21), the plane shading normal
         // (common.py:104-110) and BIAS*N of a plane hit (trace.py:82-83).
-        std::vector<double> rec((size_t)S * rt::SPH_STRIDE + (size_t)P * rt::PL_STRIDE + (size_t)L * rt::LT_STRIDE + 1, 0.0);
+        // Scenes with more than rt::CLUSTER_MIN spheres are stored in clusters of rt::CLUSTER spatially close
+        // spheres (Morton order of the centres), each with a bounding sphere the kernel culls first.  Slot
+        // order is a permutation of the caller's order; every record keeps the caller's index so that the
+        // reference's tie rule (the lower index wins an exact tie, trace.py:26) is unaffected.
+        std::vector<int> order(S);
+        std::iota(order.begin(), order.end(), 0);
+        int NC = 0;
+        if (S > rt::CLUSTER_MIN) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int k = 0; k < S; ++k)
+                for (int i = 0; i < 3; ++i) { const double v = spheres[i * S + k]; lo[i] = std::min(lo[i], v); hi[i] = std::max(hi[i], v); }
+            std::vector<uint32_t> code(S);
+            for (int k = 0; k < S; ++k) {
+                uint32_t m = 0;
+                for (int i = 0; i < 3; ++i) {
+                    const double span = hi[i] - lo[i];
+                    uint32_t q = span > 0 ? (uint32_t)std::min(1023.0, std::max(0.0, (spheres[i * S + k] - lo[i]) / span * 1023.0)) : 0u;
+                    for (int b = 0; b < 10; ++b) m |= ((q >> b) & 1u) << (3 * b + i);
+                }
+                code[k] = m;
+            }
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code[a] < code[b]; });
+            NC = (S + rt::CLUSTER - 1) / rt::CLUSTER;
+        }
+        nclusters = NC;
+        std::vector<double> rec((size_t)S * rt::SPH_STRIDE + (size_t)P * rt::PL_STRIDE + (size_t)L * rt::LT_STRIDE +
+                                (size_t)NC * rt::CL_STRIDE + 1, 0.0);
         double *sp = rec.data();
-        for (int k = 0; k < S; ++k, sp += rt::SPH_STRIDE) {
+        for (int slot = 0; slot < S; ++slot, sp += rt::SPH_STRIDE) {
+            const int k = order[slot];
+            sp[7] = (double)k;                                   // the caller's index of this sphere
             const float r = spheres[3 * S + k];
             const float r2 = r * r;
             sp[0] = spheres[0 * S + k]; sp[1] = spheres[1 * S + k]; sp[2] = spheres[2 * S + k]; sp[3] = (double)r2;
@@ -227,6 +259,20 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         for (int k = 0; k < L; ++k, sp += rt::LT_STRIDE) {
             sp[0] = lights[0 * L + k]; sp[1] = lights[1 * L + k]; sp[2] = lights[2 * L + k];
         }
+        for (int c = 0; c < NC; ++c, sp += rt::CL_STRIDE) {      // bounding sphere of cluster c (float64, inflated)
+            const int j0 = c * rt::CLUSTER, j1 = std::min(S, j0 + rt::CLUSTER);
+            double C[3] = {0, 0, 0};
+            for (int j = j0; j < j1; ++j) for (int i = 0; i < 3; ++i) C[i] += spheres[i * S + order[j]];
+            for (int i = 0; i < 3; ++i) C[i] /= (j1 - j0);
+            double R = 0;
+            for (int j = j0; j < j1; ++j) {
+                const int k = order[j];
+                const double dx = spheres[0 * S + k] - C[0], dy = spheres[1 * S + k] - C[1], dz = spheres[2 * S + k] - C[2];
+                R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)spheres[3 * S + k]));
+            }
+            R = R * (1.0 + 1e-6) + 1e-9;
+            sp[0] = C[0]; sp[1] = C[1]; sp[2] = C[2]; sp[3] = R * R;
+        }
         RT_HIP(ctx, hipSetDevice(ctx->device));
         const size_t bytes = rec.size() * sizeof(double);
         int rc = ensure(ctx, ctx->scene, bytes);
@@ -247,7 +293,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         if (x * x + y * y + z * z > ext2) ext2 = x * x + y * y + z * z;
     }
     ctx->scene_extent2 = ext2;
-    ctx->S = S; ctx->P = P; ctx->L = L;
+    ctx->S = S; ctx->P = P; ctx->L = L; ctx->NC = nclusters;
     ctx->have_scene = true;
     return RT_OK;
 }

@@ -43,9 +43,12 @@ namespace rt {
 constexpr int TILE = 8;            // 8x8 pixels per wavefront
 constexpr int WAVES_PER_WG = 4;
 constexpr int WG_THREADS = 64 * WAVES_PER_WG;
-constexpr int SPH_STRIDE = 8;      // doubles per sphere record: cx,cy,cz,r2, R,G,B,pad
+constexpr int SPH_STRIDE = 8;      // doubles per sphere record: cx,cy,cz,r2, R,G,B, caller's index
 constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, R,G,B,pad
 constexpr int LT_STRIDE = 4;       // x,y,z,pad
+constexpr int CL_STRIDE = 4;       // cluster bounding sphere: cx,cy,cz,R2 (global memory only; LDS holds the float32 tables)
+constexpr int CLUSTER = 8;         // spheres per cluster
+constexpr int CLUSTER_MIN = 16;    // scenes with at most this many spheres stay flat
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, w+margin (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
 #ifndef RT_CULL_UNROLL
@@ -61,6 +64,7 @@ struct KParams {
     long long plane_stride;    // elements between colour planes of the output
     int w, h, x0, x1;
     int S, P, L, depth;
+    int NC, pad2;              // sphere clusters (0 = flat)
     int aa, u8_rgb, tiles_y, ntiles;
     int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
     unsigned seed, pad0;       // jitter hash seed (stochastic AA)
@@ -219,8 +223,11 @@ constexpr float CULL_K_FLOOR = 0x1p-40f;
 
 struct Lds {
     const double *rec;     // float64 records
-    const float *sph32;    // S x {cx,cy,cz,r2}
-    const float *tab;      // anchors x S x CULL_STRIDE
+    const float *sph32;    // Sp x {cx,cy,cz,r2}
+    const float *tab;      // anchors x Sp x CULL_STRIDE
+    const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
+    const float *ctab;     // anchors x NCp x CULL_STRIDE: cluster bounding spheres, anchored form
+    int NC;
     double *acc;           // 6 (9 with AA) x WG_THREADS doubles, [slot][thread] (consecutive lanes -> consecutive banks):
                            // slots 0-2 the running colour of the current sample, 3-5 the incoming direction
                            // during the light loop, 6-8 (AA kernel only) the tap sums — kept out of VGPRs that would stay
@@ -280,34 +287,52 @@ __device__ __forceinline__ unsigned long long any_lane(bool pred)
     return r;
 }
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+// sphere slots in the float32 tables: whole clusters when the scene is clustered, else a multiple of 4
+__host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTER : pad4(S); }
 
-// Both float32 tables are padded to a multiple of 4 spheres with entries that always certify a miss
-// (w = -inf), so the 4-way unrolled groups below need no bounds handling and use immediate LDS offsets
-// (the compiler packs the four independent chains into v_pk_mul/fma_f32, two spheres per instruction).
+// Certificates of 4 consecutive table entries -> 4 mask bits (bit u set = some live lane has no certificate).
+// The tables are padded with entries that always certify a miss (w = -inf), so groups of 4 need no bounds
+// handling and use immediate LDS offsets (the compiler packs the four independent chains into
+// v_pk_mul/fma_f32, two spheres per instruction).
+__device__ __forceinline__ unsigned cull4(const float *__restrict__ base, bool anchored, const RayF &q, int jsel)
+{
+    unsigned bits = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool culled = (anchored ? cull_anchored(base + u * CULL_STRIDE, q) : cull_origin(base + 4 * u, q)) || (u == jsel);
+        bits |= (unsigned)any_lane(!culled) << u;
+    }
+    return bits;
+}
+
+// Phase 1 of a scene query for the chunk of spheres [k0, k0+n), k0 a multiple of 64: one bit per sphere, set
+// when SOME live lane holds no certificate.  Clustered scenes first test the (up to 8) bounding spheres of the
+// chunk's clusters and only open the clusters some lane might hit.  Everything here is wave-uniform control
+// flow on scalar masks.
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
                                                         const RayF &q, int self, bool self_culled)
 {
     unsigned long long mask = 0ull;
-    const int Sp = pad4(S), npad = pad4(n);
+    const bool anchored = anchor >= 0;
+    const int Sp = padS(S, lds.NC);
     const int selfj = self_culled ? self - k0 : -1;                           // per lane
-    if (anchor >= 0) {
-        const float *tab = lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE;
-        for (int j = 0; j < npad; j += CULL_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < CULL_UNROLL; ++u) {
-                const bool culled = cull_anchored(tab + (j + u) * CULL_STRIDE, q) || (j + u == selfj);
-                mask |= any_lane(!culled) << (j + u);
-            }
+    const float *sbase = anchored ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0;
+    if (lds.NC > 0) {
+        const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
+        const float *cbase = anchored ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0;
+        unsigned cm = 0;
+        for (int j = 0; j < nc; j += 4) cm |= cull4(cbase + j * 4, anchored, q, -1) << j;
+        while (cm) {                                                          // clusters some lane might hit
+            const int c = __builtin_ctz(cm);
+            cm &= cm - 1u;
+            const int jb = c * CLUSTER;
+            const unsigned lo = cull4(sbase + jb * 4, anchored, q, selfj - jb);
+            const unsigned hi = cull4(sbase + (jb + 4) * 4, anchored, q, selfj - jb - 4);
+            mask |= (unsigned long long)(lo | (hi << 4)) << jb;
         }
     } else {
-        const float *sp = lds.sph32 + 4 * k0;
-        for (int j = 0; j < npad; j += CULL_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < CULL_UNROLL; ++u) {
-                const bool culled = cull_origin(sp + 4 * (j + u), q);
-                mask |= any_lane(!culled) << (j + u);
-            }
-        }
+        const int npad = pad4(n);
+        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4(sbase + j * 4, anchored, q, selfj - j) << j;
     }
     return mask;
 }
@@ -334,7 +359,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #if RT_PREFILTER
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
-    double bestn = __builtin_inf();
+    double bestn = __builtin_inf(), borig = 0.0;
     int bidx = -1;
     for (int k0 = 0; k0 < (RT_ABLATE == 3 ? 0 : S); k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
@@ -359,7 +384,9 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
             const double q = __builtin_sqrt(D);
             double n = -s - q;                                // :28
             if (!(n > 0.0)) n = -s + q;                       // :33
-            if (n > 0.0 && n < bestn) { bestn = n; bidx = k; }   // first smallest wins (strict <), trace.py:26
+            // the smallest wins and, on an exact tie, the lower caller's index (trace.py:26: strict <, ascending
+            // order) — slots are visited in slot order, which for clustered scenes is a permutation
+            if (n > 0.0 && (n < bestn || (n == bestn && g[7] < borig))) { bestn = n; bidx = k; borig = g[7]; }
         }
       }
     }
@@ -588,11 +615,11 @@ __device__ __forceinline__ uint8_t clip_color(double c)
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
 __host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x WG_THREADS doubles
 __host__ __device__ inline int lds_offset_words(bool park) { return park ? WG_THREADS : 0; }    // + one int32 per thread: the pixel offset
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int anchors, bool aa, bool park)
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park)
 {
     return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) +
-           ((size_t)lds_offset_words(park) + (size_t)pad4(S) * 4) * sizeof(float) +
-           (size_t)anchors * pad4(S) * CULL_STRIDE * sizeof(float);
+           ((size_t)lds_offset_words(park) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
+           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float);
 }
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
@@ -611,8 +638,10 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
     double *accum = lds_raw + nrec;
     int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK) * WG_THREADS);
     float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK));
-    const int Sp = pad4(p.S);
-    float *tab = sph32 + 4 * Sp;
+    const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
+    float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
+    float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
+    float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
     {   // stage the packed scene once per workgroup
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
     }
@@ -640,10 +669,33 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
             t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
             t[3] = (float)((g[3] - ll) + (ll + g[3]) * (double)CULL_K_ANCHOR);     // w + margin
         }
+        // the same two tables for the cluster bounding spheres (float64 records in global memory, after the
+        // lights; rounding the centre to float32 is covered by rounding R2 up)
+        const double *cl = p.scene + nrec;
+        for (int c = threadIdx.x; c < NCp; c += WG_THREADS) {
+            const bool real = c < p.NC;
+            const double *g = cl + (real ? c : 0) * CL_STRIDE;
+            csph32[4 * c + 0] = real ? (float)g[0] : 0.0f; csph32[4 * c + 1] = real ? (float)g[1] : 0.0f;
+            csph32[4 * c + 2] = real ? (float)g[2] : 0.0f;
+            csph32[4 * c + 3] = real ? (float)(g[3] * (1.0 + 0x1p-20)) : NINF;
+        }
+        for (int e = threadIdx.x; e < p.anchors * NCp; e += WG_THREADS) {
+            const int a = e / NCp, c = e - a * NCp;
+            float *t = ctab + (size_t)e * CULL_STRIDE;
+            if (c >= p.NC) { t[0] = t[1] = t[2] = 0.0f; t[3] = NINF; continue; }
+            const double *g = cl + c * CL_STRIDE;
+            const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
+            const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
+            const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
+            const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
+            const double ll = lx * lx + ly * ly + lz * lz;
+            t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
+            t[3] = (float)((g[3] - ll) + (ll + g[3]) * (double)CULL_K_ANCHOR);
+        }
     }
     __syncthreads();
 #endif
-    const Lds lds{lds_raw, sph32, tab, accum};
+    const Lds lds{lds_raw, sph32, tab, csph32, ctab, p.NC, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * WAVES_PER_WG + wave;
