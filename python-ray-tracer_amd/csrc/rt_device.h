@@ -48,7 +48,10 @@ constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, 
 constexpr int LT_STRIDE = 4;       // x,y,z,pad
 constexpr int CL_STRIDE = 4;       // cluster bounding sphere: cx,cy,cz,R2 (global memory only; LDS holds the float32 tables)
 constexpr int CLUSTER = 8;         // spheres per cluster
-constexpr int CLUSTER_MIN = 16;    // scenes with at most this many spheres stay flat
+#ifndef RT_CLUSTER_MIN
+#define RT_CLUSTER_MIN 96   // measured: flat wins at S=64 (1.62 vs 1.79 ms), clusters win at S=256 (27.9 vs 39.4 ms)
+#endif
+constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, w+margin (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
 #ifndef RT_CULL_UNROLL
@@ -294,12 +297,15 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // The tables are padded with entries that always certify a miss (w = -inf), so groups of 4 need no bounds
 // handling and use immediate LDS offsets (the compiler packs the four independent chains into
 // v_pk_mul/fma_f32, two spheres per instruction).
-__device__ __forceinline__ unsigned cull4(const float *__restrict__ base, bool anchored, const RayF &q, int jsel)
+template <bool ANCH>
+__device__ __forceinline__ unsigned cull4(const float *__restrict__ base, const RayF &q, int jsel)
 {
     unsigned bits = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const bool culled = (anchored ? cull_anchored(base + u * CULL_STRIDE, q) : cull_origin(base + 4 * u, q)) || (u == jsel);
+        bool culled;
+        if constexpr (ANCH) culled = cull_anchored(base + u * CULL_STRIDE, q); else culled = cull_origin(base + 4 * u, q);
+        culled = culled || (u == jsel);
         bits |= (unsigned)any_lane(!culled) << u;
     }
     return bits;
@@ -309,32 +315,38 @@ __device__ __forceinline__ unsigned cull4(const float *__restrict__ base, bool a
 // when SOME live lane holds no certificate.  Clustered scenes first test the (up to 8) bounding spheres of the
 // chunk's clusters and only open the clusters some lane might hit.  Everything here is wave-uniform control
 // flow on scalar masks.
-__device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const RayF &q, int self, bool self_culled)
+template <bool ANCH>
+__device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S, int anchor, int k0, int n,
+                                                          const RayF &q, int selfj)
 {
     unsigned long long mask = 0ull;
-    const bool anchored = anchor >= 0;
     const int Sp = padS(S, lds.NC);
-    const int selfj = self_culled ? self - k0 : -1;                           // per lane
-    const float *sbase = anchored ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0;
+    const float *sbase = ANCH ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0;
     if (lds.NC > 0) {
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
-        const float *cbase = anchored ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0;
+        const float *cbase = ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0;
         unsigned cm = 0;
-        for (int j = 0; j < nc; j += 4) cm |= cull4(cbase + j * 4, anchored, q, -1) << j;
+        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH>(cbase + j * 4, q, -1) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
             cm &= cm - 1u;
             const int jb = c * CLUSTER;
-            const unsigned lo = cull4(sbase + jb * 4, anchored, q, selfj - jb);
-            const unsigned hi = cull4(sbase + (jb + 4) * 4, anchored, q, selfj - jb - 4);
+            const unsigned lo = cull4<ANCH>(sbase + jb * 4, q, selfj - jb);
+            const unsigned hi = cull4<ANCH>(sbase + (jb + 4) * 4, q, selfj - jb - 4);
             mask |= (unsigned long long)(lo | (hi << 4)) << jb;
         }
     } else {
         const int npad = pad4(n);
-        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4(sbase + j * 4, anchored, q, selfj - j) << j;
+        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH>(sbase + j * 4, q, selfj - j) << j;
     }
     return mask;
+}
+
+__device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
+                                                        const RayF &q, int self, bool self_culled)
+{
+    const int selfj = self_culled ? self - k0 : -1;                           // per lane
+    return (anchor >= 0) ? cull_mask_t<true>(lds, S, anchor, k0, n, q, selfj) : cull_mask_t<false>(lds, S, anchor, k0, n, q, selfj);
 }
 
 // ---------------------------------------------------------------------------------------------
