@@ -62,6 +62,9 @@ typedef enum rt_status {
                                 the variant pinned by the golden vectors) */
 #define RT_FLAG_U8_RGB 2     /* store the uint8 frame as (R,G,B); default is the reference's
                                 (R,B,G) order (common.py:60-63) */
+#define RT_FLAG_NO_FEEDBACK 4 /* dispatch tiles in plain order; by default a launch dispatches its workgroups
+                                longest-first using the per-tile cycles the previous launch of the same
+                                geometry recorded (same pixels either way) */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -157,6 +160,11 @@ int rt_timer_begin(rt_ctx *ctx, void *stream);
 int rt_timer_end(rt_ctx *ctx, void *stream, float *ms);
 
 int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info);
+
+/* Statistics: with a non-NULL device buffer of ceil((x1-x0)/8) * ceil(h/8) uint32, every later launch stores
+ * the shader-clock cycles each 8x8 tile's wavefront took, tile index = tile_x * ceil(h/8) + tile_y
+ * (what the reference's unused `timed` decorator, viewer/image.py:22-34, gestures at).  NULL turns it off. */
+int rt_set_tile_stats(rt_ctx *ctx, void *d_cycles);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 RT_AA_NONE, RT_AA_REFERENCE, RT_AA_STOCHASTIC = 0, 1, 2
 RT_MAX_SPP = 64
-RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB = 1, 2
+RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB, RT_FLAG_NO_FEEDBACK = 1, 2, 4
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_DEVICE", -4: "RT_ERR_STATE", -5: "RT_ERR_ALLOC"}
 
@@ -44,6 +44,7 @@ PROTOTYPES = {
     "rt_timer_begin": (C.c_int, [_vp, _vp]),
     "rt_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "rt_get_kernel_info": (C.c_int, [_vp, C.POINTER(rt_kernel_info)]),
+    "rt_set_tile_stats": (C.c_int, [_vp, _vp]),
     "rt_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rt_free": (C.c_int, [_vp, _vp]),
     "rt_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -39,6 +39,15 @@ struct rt_ctx {
     int w = 0, h = 0;
     double px = 0, y0 = 0, dy = 0, z0 = 0, dz = 0;
     size_t lds_limit_set = 0;
+    unsigned *tile_stats = nullptr;   // caller-owned device buffer or NULL
+    // Scheduler feedback: a launch files its tile blocks by cost; a small kernel behind it (same stream) turns
+    // that into the dispatch order of the next launch.  (Running that kernel on a side stream, overlapped with
+    // the next render, was measured slower: the cross-stream event waits cost more than the 8 us they hide.)
+    struct Feedback {
+        Buf hist, slot, order;        // cost histogram, per-block (bucket, rank), dispatch order
+        long long key = -1;           // launch geometry `order` was built for (-1: none)
+        hipStream_t stream = nullptr; // stream it was built on
+    } fb;
     std::string err;
 };
 
@@ -101,6 +110,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.pixel_loc = ctx->explicit_grid ? (const double *)ctx->pixel_loc.p : nullptr;
     k.out_u8 = (uint8_t *)d_u8;
     k.out_f32 = (float *)d_f32;
+    k.tile_cycles = ctx->tile_stats;
     k.plane_stride = plane_stride;
     k.w = ctx->w; k.h = ctx->h; k.x0 = x0; k.x1 = x1;
     k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth; k.NC = ctx->NC;
@@ -135,8 +145,36 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         ctx->lds_limit_set = lds;
     }
     const unsigned grid = (unsigned)((k.ntiles + rt::WAVES_PER_WG - 1) / rt::WAVES_PER_WG);
+    // Scheduler feedback (longest-first dispatch): a launch files its tile blocks by cost and dispatches in the
+    // order built from the previous launch if that ran on the same stream with the same geometry.
+    // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
+    const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
+    const long long key = ((long long)x0 << 42) ^ ((long long)x1 << 21) ^ (long long)ctx->h ^ ((long long)k.aa << 62);
+    rt_ctx::Feedback &f = ctx->fb;
+    if (feedback) {
+        if (!f.hist.p) {
+            int rc0 = ensure(ctx, f.hist, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned));
+            if (rc0 != RT_OK) return rc0;
+            RT_HIP(ctx, hipMemsetAsync(f.hist.p, 0, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned), stream));
+        }
+        if (f.slot.cap < (size_t)grid * sizeof(unsigned) || f.order.cap < (size_t)grid * sizeof(unsigned)) f.key = -1;
+        int rc = ensure(ctx, f.slot, (size_t)grid * sizeof(unsigned));
+        if (rc == RT_OK) rc = ensure(ctx, f.order, (size_t)grid * sizeof(unsigned));
+        if (rc != RT_OK) return rc;
+        k.hist = (unsigned *)f.hist.p;
+        k.slot = (unsigned *)f.slot.p;
+        k.order = (f.key == key && f.stream == stream) ? (const unsigned *)f.order.p : nullptr;
+    }
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(rt::WG_THREADS), args, lds, stream));
+    if (feedback) {
+        hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
+                           (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid);
+        f.key = key;
+        f.stream = stream;
+    } else {
+        f.key = -1;
+    }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -185,7 +223,7 @@ int rt_destroy(rt_ctx *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32})
+    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->fb.hist, &ctx->fb.slot, &ctx->fb.order})
         if (b->p) (void)hipFree(b->p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -427,6 +465,13 @@ int rt_timer_end(rt_ctx *ctx, void *stream, float *ms)
     RT_HIP(ctx, hipEventRecord(ctx->ev1, stream ? (hipStream_t)stream : ctx->stream));
     RT_HIP(ctx, hipEventSynchronize(ctx->ev1));
     RT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RT_OK;
+}
+
+int rt_set_tile_stats(rt_ctx *ctx, void *d_cycles)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    ctx->tile_stats = (unsigned *)d_cycles;
     return RT_OK;
 }
 

@@ -64,6 +64,10 @@ struct KParams {
     const double *pixel_loc;   // explicit (3,w,h) grid or nullptr (closed-form ray generation)
     uint8_t *out_u8;           // or nullptr
     float *out_f32;            // or nullptr
+    unsigned *tile_cycles;     // or nullptr: per-tile wave cycles of this launch (rt_set_tile_stats)
+    unsigned *hist;            // or nullptr: scheduler feedback, 1024 cost buckets (zero on entry)
+    unsigned *slot;            // per tile block: (bucket << 20) | arrival rank within the bucket
+    const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from the previous launch's costs
     long long plane_stride;    // elements between colour planes of the output
     int w, h, x0, x1;
     int S, P, L, depth;
@@ -290,6 +294,14 @@ __device__ __forceinline__ unsigned long long any_lane(bool pred)
     return r;
 }
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+
+// logarithmic cost key for the dispatch-order feedback: monotone in c, < 1024
+__device__ __forceinline__ int order_bucket(unsigned c)
+{
+    if (c < 32u) return (int)c;
+    const int msb = 31 - __builtin_clz(c);
+    return ((msb - 4) << 5) | (int)((c >> (msb - 5)) & 31u);
+}
 // sphere slots in the float32 tables: whole clusters when the scene is clustered, else a multiple of 4
 __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTER : pad4(S); }
 
@@ -631,7 +643,7 @@ __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anc
 {
     return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) +
            ((size_t)lds_offset_words(park) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
-           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float);
+           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + 16;   // + workgroup cost/arrival words
 }
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
@@ -654,6 +666,8 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
     float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
     float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
     float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
+    unsigned *wgstat = reinterpret_cast<unsigned *>(ctab + (size_t)p.anchors * NCp * CULL_STRIDE);   // {cycles, waves done}
+    if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene once per workgroup
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
     }
@@ -710,8 +724,13 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
     const Lds lds{lds_raw, sph32, tab, csph32, ctab, p.NC, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * WAVES_PER_WG + wave;
+    // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
+    // permutation of the tile blocks sorted by the cycles they took in the previous launch (order_kernel).
+    // Any permutation renders every tile exactly once; only the length of the launch's tail depends on it.
+    const int block = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;
+    const int tile = block * WAVES_PER_WG + wave;
     if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
+    const unsigned long long t_begin = (p.tile_cycles || p.hist) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
     const int x = p.x0 + tx * TILE + (lane >> 3);
     const int y = ty * TILE + (lane & 7);
@@ -778,6 +797,54 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
             p.out_f32[p.plane_stride + off] = (float)G;
             p.out_f32[2 * p.plane_stride + off] = (float)B;
         }
+    }
+    if ((p.tile_cycles || p.hist) && (threadIdx.x & 63) == 0) {               // timing only; never feeds a pixel
+        const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+        if (p.tile_cycles) p.tile_cycles[block * WAVES_PER_WG + (threadIdx.x >> 6)] = cyc;
+        if (p.hist) {
+            // the workgroup's cost = sum over its waves; the wave that finishes last files the block under its
+            // cost bucket and records its arrival rank there (one device atomic per workgroup)
+            const int expected = (p.ntiles - block * WAVES_PER_WG < WAVES_PER_WG) ? p.ntiles - block * WAVES_PER_WG : WAVES_PER_WG;
+            atomicAdd(&wgstat[0], cyc >> 2);
+            if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) {
+                const int bkt = order_bucket(atomicAdd(&wgstat[0], 0u));
+                p.slot[block] = ((unsigned)bkt << 20) | atomicAdd(&p.hist[bkt], 1u);
+            }
+        }
+    }
+}
+
+// Builds the next launch's dispatch order from what this launch recorded: tile blocks (4 tiles = one workgroup)
+// sorted by decreasing cost — a counting sort on a 1024-bucket logarithmic key (5 mantissa bits per octave)
+// whose histogram and within-bucket ranks the render kernel has already produced.  What is left is a prefix sum
+// over the buckets and one scatter; the output is a permutation of [0, nblocks) by construction (distinct
+// (bucket, rank) pairs map to distinct positions).  Also re-zeroes the histogram for the next launch.
+constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 1024;
+__global__ __launch_bounds__(ORDER_THREADS) void order_kernel(unsigned *__restrict__ hist, const unsigned *__restrict__ slot,
+                                                               unsigned *__restrict__ order, int nblocks)
+{
+    __shared__ unsigned start[ORDER_BUCKETS];
+    __shared__ unsigned scan[ORDER_BUCKETS];
+    const int i = threadIdx.x;                          // ORDER_THREADS == ORDER_BUCKETS; thread i owns bucket 1023-i
+    const unsigned v = hist[ORDER_BUCKETS - 1 - i];
+    hist[ORDER_BUCKETS - 1 - i] = 0u;
+    // inclusive scan in descending key order: shuffles inside each of the 16 waves, then the wave totals
+    unsigned incl = v;
+    const int lane = i & 63, wv = i >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) scan[wv] = incl;                    // wave totals
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wv; ++w) base += scan[w];
+    start[ORDER_BUCKETS - 1 - i] = base + incl - v;     // exclusive offset of bucket 1023-i
+    __syncthreads();
+    for (int b = i; b < nblocks; b += ORDER_THREADS) {
+        const unsigned s = slot[b];
+        order[start[s >> 20] + (s & 0xFFFFFu)] = (unsigned)b;
     }
 }
 

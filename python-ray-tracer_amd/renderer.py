@@ -143,6 +143,10 @@ class Renderer:
         self._check(self._lib.rt_timer_end(self._ctx, C.c_void_p(stream) if stream else None, C.byref(ms)))
         return ms.value
 
+    def set_tile_stats(self, dptr):
+        """Device buffer (uint32 per 8x8 tile) that later launches fill with per-tile wave cycles; None = off."""
+        self._check(self._lib.rt_set_tile_stats(self._ctx, C.c_void_p(dptr) if dptr else None))
+
     def kernel_info(self):
         info = L.rt_kernel_info()
         self._check(self._lib.rt_get_kernel_info(self._ctx, C.byref(info)))

@@ -214,3 +214,39 @@ def test_error_behaviour(renderer):
     with pytest.raises(pkg.RenderError):
         pkg.Renderer(10_000)                  # no such device
     r.close()
+
+
+def test_feedback_dispatch_order_never_changes_pixels(renderer):
+    """Longest-first dispatch: from the second launch of a geometry on, workgroups run in the order built from
+    the previous launch's per-tile cycles.  Every launch must still produce the reference frame."""
+    from python_ray_tracer_amd import _lib as L
+    g = load_frame("default_128_d3")
+    _setup(renderer, g)
+    for _ in range(5):
+        u8, f32 = _render(renderer, g)
+        assert np.array_equal(u8, g["frame_u8"])
+    plain8, plain32 = _render(renderer, g, flags=L.RT_FLAG_NO_FEEDBACK)
+    assert np.array_equal(plain8, g["frame_u8"]) and np.array_equal(plain32, f32)
+    # geometry changes in between (slabs), then back
+    a8, _ = _render(renderer, g, x0=8, x1=72)
+    b8, _ = _render(renderer, g, x0=8, x1=72)
+    assert np.array_equal(a8, g["frame_u8"][:, 8:72]) and np.array_equal(b8, a8)
+    u8, _ = _render(renderer, g)
+    assert np.array_equal(u8, g["frame_u8"])
+
+
+def test_tile_stats(renderer):
+    g = load_frame("default_128_d3")
+    w, h, _ = _setup(renderer, g)
+    ntiles = ((w + 7) // 8) * ((h + 7) // 8)
+    d = renderer.malloc(4 * ntiles)
+    try:
+        renderer.h2d(d, np.zeros(ntiles, np.uint32))
+        renderer.set_tile_stats(d)
+        u8, _ = _render(renderer, g)
+        cyc = np.empty(ntiles, np.uint32)
+        renderer.d2h(cyc, d)
+        assert np.array_equal(u8, g["frame_u8"]) and (cyc > 0).all() and cyc.max() < 50_000_000
+    finally:
+        renderer.set_tile_stats(None)
+        renderer.free(d)

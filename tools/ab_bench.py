@@ -28,18 +28,22 @@ def main():
     wl = workloads.build(a.workload or workloads.HEADLINE)
     cam, w, h = wl["camera"], wl["w"], wl["h"]
     rs = []
-    for path in a.libs:
-        r = pkg.Renderer(0, lib=_lib.bind(os.path.abspath(path)))
+    flags = {}
+    for path in a.libs:                      # "build.so" or "build.so:FLAGS" (rt_params.flags, e.g. :4 = no scheduler feedback)
+        so, _, fl = path.partition(":")
+        flags[path] = int(fl or 0)
+        r = pkg.Renderer(0, lib=_lib.bind(os.path.abspath(so)))
         r.set_scene(wl["spheres"], wl["lights"], wl["planes"]); r.set_camera(cam.position, cam.rotation); r.set_raygen(w, h, *cam.raygen())
         d8, d32 = r.malloc(3 * w * h), r.malloc(12 * w * h)
         rs.append((path, r, d8, d32))
-    p = pkg.Renderer.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 1 if a.aa else wl["aa"], spp=wl["spp"], seed=wl["seed"])
+    ps = {path: pkg.Renderer.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 1 if a.aa else wl["aa"], flags=flags[path],
+                                    spp=wl["spp"], seed=wl["seed"]) for path in a.libs}
     times = {path: [] for path, *_ in rs}
     for rnd in range(a.rounds + 2):
         for path, r, d8, d32 in rs:
             r.timer_begin()
             for _ in range(a.launches):
-                r.render_device(p, 0, w, d8, d32, w * h)
+                r.render_device(ps[path], 0, w, d8, d32, w * h)
             ms = r.timer_end() / a.launches
             if rnd >= 2:
                 times[path].append(ms)
