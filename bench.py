@@ -49,8 +49,8 @@ def cpu_baseline(wl, rays_per_frame, min_wall_s=2.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, help="one of python_ray_tracer_amd.workloads.CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -99,18 +99,14 @@ def main():
     busy = [False] * SLOTS
     frame = None
 
-    def step(i, ev=None):
+    def step(i):
         nonlocal frame
         b = i % SLOTS
         if gatherer is not None and busy[b]:            # the slab is reused: its gather must have completed
             f = gatherer.finish(b)
             frame = f if f is not None else frame
             busy[b] = False
-        if ev:
-            ev[0].record()
         r.render_device(params, x0, x1, slabs_u8[b].data_ptr(), slab_f32.data_ptr(), ws * h, stream)
-        if ev:
-            ev[1].record()
         if gatherer is not None:
             gatherer.submit(slabs_u8[b], b)
             busy[b] = True
@@ -134,15 +130,20 @@ def main():
     for i in range(a.warmup):
         step(i)
     drain()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # One HIP event pair on the launch stream around the whole timed region: elapsed / K is the mean duration
+    # of one launch of the path (render kernel + its ~8 us dispatch-order kernel + launch gaps; with N > 1 also
+    # whatever part of the gather does not overlap) — a conservative kernel time for the roofline.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(a.steps):
-        step(i, events[i])
+        step(i)
+    ev1.record()
     drain()                                             # every one of the K frames is assembled on rank 0
     fence()
     dt = time.perf_counter() - t0
-    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(a.steps, 1)
+    kernel_ms = ev0.elapsed_time(ev1) / max(a.steps, 1)
 
     t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
