@@ -309,7 +309,7 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // The tables are padded with entries that always certify a miss (w = -inf), so groups of 4 need no bounds
 // handling and use immediate LDS offsets (the compiler packs the four independent chains into
 // v_pk_mul/fma_f32, two spheres per instruction).
-template <bool ANCH>
+template <bool ANCH, bool SELF>
 __device__ __forceinline__ unsigned cull4(const float *__restrict__ base, const RayF &q, int jsel)
 {
     unsigned bits = 0;
@@ -317,7 +317,7 @@ __device__ __forceinline__ unsigned cull4(const float *__restrict__ base, const 
     for (int u = 0; u < 4; ++u) {
         bool culled;
         if constexpr (ANCH) culled = cull_anchored(base + u * CULL_STRIDE, q); else culled = cull_origin(base + 4 * u, q);
-        culled = culled || (u == jsel);
+        if constexpr (SELF) culled = culled || (u == jsel);   // the sphere this lane's shadow ray starts on
         bits |= (unsigned)any_lane(!culled) << u;
     }
     return bits;
@@ -327,7 +327,7 @@ __device__ __forceinline__ unsigned cull4(const float *__restrict__ base, const 
 // when SOME live lane holds no certificate.  Clustered scenes first test the (up to 8) bounding spheres of the
 // chunk's clusters and only open the clusters some lane might hit.  Everything here is wave-uniform control
 // flow on scalar masks.
-template <bool ANCH>
+template <bool ANCH, bool SELF>
 __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S, int anchor, int k0, int n,
                                                           const RayF &q, int selfj)
 {
@@ -338,18 +338,18 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
         const float *cbase = ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0;
         unsigned cm = 0;
-        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH>(cbase + j * 4, q, -1) << j;
+        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j * 4, q, -1) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
             cm &= cm - 1u;
             const int jb = c * CLUSTER;
-            const unsigned lo = cull4<ANCH>(sbase + jb * 4, q, selfj - jb);
-            const unsigned hi = cull4<ANCH>(sbase + (jb + 4) * 4, q, selfj - jb - 4);
+            const unsigned lo = cull4<ANCH, SELF>(sbase + jb * 4, q, selfj - jb);
+            const unsigned hi = cull4<ANCH, SELF>(sbase + (jb + 4) * 4, q, selfj - jb - 4);
             mask |= (unsigned long long)(lo | (hi << 4)) << jb;
         }
     } else {
         const int npad = pad4(n);
-        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH>(sbase + j * 4, q, selfj - j) << j;
+        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j * 4, q, selfj - j) << j;
     }
     return mask;
 }
@@ -358,7 +358,9 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
                                                         const RayF &q, int self, bool self_culled)
 {
     const int selfj = self_culled ? self - k0 : -1;                           // per lane
-    return (anchor >= 0) ? cull_mask_t<true>(lds, S, anchor, k0, n, q, selfj) : cull_mask_t<false>(lds, S, anchor, k0, n, q, selfj);
+    if (__ballot(self_culled) != 0ull)                                        // only shadow rays leaving a sphere
+        return (anchor >= 0) ? cull_mask_t<true, true>(lds, S, anchor, k0, n, q, selfj) : cull_mask_t<false, true>(lds, S, anchor, k0, n, q, selfj);
+    return (anchor >= 0) ? cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1) : cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1);
 }
 
 // ---------------------------------------------------------------------------------------------
