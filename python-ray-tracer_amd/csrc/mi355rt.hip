@@ -288,6 +288,11 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
             plane_normal_f32(nraw, nf);
             const double BIAS = 0.0002;
             const float bf = (float)BIAS;
+            {   // axis code: the stored normal is exactly +-e_i (intersection shortcut in rt_device.h:plane_den_num)
+                int axis = -1, nonzero = 0;
+                for (int i = 0; i < 3; ++i) if (nraw[i] != 0.0f) { ++nonzero; axis = i; }
+                sp[15] = (nonzero == 1 && (nraw[axis] == 1.0f || nraw[axis] == -1.0f)) ? (double)(axis + 1) * (double)nraw[axis] : 0.0;
+            }
             for (int i = 0; i < 3; ++i) {
                 sp[6 + i] = (double)nf[i];
                 sp[9 + i] = (flags & RT_FLAG_TYPED_BIAS) ? BIAS * (double)nf[i] : (double)(bf * nf[i]);

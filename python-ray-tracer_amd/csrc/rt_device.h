@@ -44,7 +44,7 @@ constexpr int TILE = 8;            // 8x8 pixels per wavefront
 constexpr int WAVES_PER_WG = 4;
 constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 constexpr int SPH_STRIDE = 8;      // doubles per sphere record: cx,cy,cz,r2, R,G,B, caller's index
-constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, R,G,B,pad
+constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, R,G,B, axis code (0 general, +-1/2/3 = +-e_x/y/z)
 constexpr int LT_STRIDE = 4;       // x,y,z,pad
 constexpr int CL_STRIDE = 4;       // cluster bounding sphere: cx,cy,cz,R2 (global memory only; LDS holds the float32 tables)
 constexpr int CLUSTER = 8;         // spheres per cluster
@@ -373,6 +373,29 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
 // the reference returns a miss, and so do we without evaluating the sqrt.
 // ---------------------------------------------------------------------------------------------
 
+// intersections.py:52 and :59-61 for one plane record: den = d.n and num = (p0 - o).n.  A plane whose stored
+// normal is exactly +-e_i (the reference's ground plane is (0,0,1)) has den = +-d_i and num = +-(p0_i - o_i)
+// bit for bit — the other two products are +-0 and add nothing — so 8 of the 13 operations are skipped under a
+// wave-uniform branch on the record's axis code (set by the host).
+__device__ __forceinline__ void plane_den_num(const double *__restrict__ g, const V3 &o, const V3 &d, double &den, double &num)
+{
+    const double code = g[15];
+    if (code == 0.0) {
+        const V3 n{g[3], g[4], g[5]};
+        den = dot3(d, n);
+        const V3 LP{g[0] - o.x, g[1] - o.y, g[2] - o.z};
+        num = dot3(LP, n);
+    } else {
+        const double a = __builtin_fabs(code);
+        double dc, lp;
+        if (a == 1.0)      { dc = d.x; lp = g[0] - o.x; }
+        else if (a == 2.0) { dc = d.y; lp = g[1] - o.y; }
+        else               { dc = d.z; lp = g[2] - o.z; }
+        den = code > 0.0 ? dc : -dc;
+        num = code > 0.0 ? lp : -lp;
+    }
+}
+
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
@@ -425,11 +448,10 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     const double *pl = lds.rec + S * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {                             // intersections.py:41-68
         const double *g = pl + k * PL_STRIDE;
-        const V3 n{g[3], g[4], g[5]};
-        const double den = dot3(d, n);                        // :52
+        double den, num;
+        plane_den_num(g, o, d, den, num);                     // :52, :59-61
         if (!(__builtin_fabs(den) < 0.001)) {                 // :55
-            const V3 LP{g[0] - o.x, g[1] - o.y, g[2] - o.z};  // :59
-            const double t = dot3(LP, n) / den;               // :61-63
+            const double t = num / den;                       // :63
             if (best > t && t > 0.0) { best = t; idx = k; type = HIT_PLANE; }
         }
     }
@@ -497,11 +519,9 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         if (__ballot(!occ) == 0ull) break;
         if (!occ) {
             const double *g = pl + k * PL_STRIDE;
-            const V3 n{g[3], g[4], g[5]};
-            const double den = dot3(d, n);
+            double den, num;
+            plane_den_num(g, o, d, den, num);
             if (!(__builtin_fabs(den) < 0.001)) {
-                const V3 LP{g[0] - o.x, g[1] - o.y, g[2] - o.z};
-                const double num = dot3(LP, n);
                 const double an = __builtin_fabs(num), ad = __builtin_fabs(den);
                 const bool same_sign = (num > 0.0 && den > 0.0) || (num < 0.0 && den < 0.0);
                 if (same_sign) {
