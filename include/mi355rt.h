@@ -62,6 +62,9 @@ typedef enum rt_status {
                                 the variant pinned by the golden vectors) */
 #define RT_FLAG_U8_RGB 2     /* store the uint8 frame as (R,G,B); default is the reference's
                                 (R,B,G) order (common.py:60-63) */
+#define RT_FLAG_U8_HWC 8     /* store the uint8 frame as an image, [y][x][3] interleaved (what viewer/image.py:7-19
+                                builds on the host from the (3,w,h) frame); plane_stride is then the row pitch in
+                                pixels (x1-x0 for a compact slab); uint8 output only */
 #define RT_FLAG_NO_FEEDBACK 4 /* dispatch tiles in plain order; by default a launch dispatches its workgroups
                                 longest-first using the per-tile cycles the previous launch of the same
                                 geometry recorded (same pixels either way) */

@@ -114,7 +114,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.plane_stride = plane_stride;
     k.w = ctx->w; k.h = ctx->h; k.x0 = x0; k.x1 = x1;
     k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth; k.NC = ctx->NC;
-    k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0;
+    k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0; k.u8_hwc = (p->flags & RT_FLAG_U8_HWC) ? 1 : 0;
     k.spp = p->spp; k.seed = p->seed;
     k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
     const int tiles_x = (x1 - x0 + rt::TILE - 1) / rt::TILE;
@@ -384,7 +384,10 @@ int rt_render_device(rt_ctx *ctx, const rt_params *params, int x0, int x1, void 
     int rc = check_params(ctx, params, x0, x1);
     if (rc != RT_OK) return rc;
     if (!d_u8 && !d_f32) return fail(ctx, RT_ERR_BAD_ARG, "both output pointers are NULL");
-    if (plane_stride < (int64_t)(x1 - x0) * ctx->h) return fail(ctx, RT_ERR_BAD_ARG, "plane_stride smaller than the slab");
+    if (params->flags & RT_FLAG_U8_HWC) {
+        if (d_f32) return fail(ctx, RT_ERR_BAD_ARG, "RT_FLAG_U8_HWC re-uses plane_stride as the image row pitch: render the float32 buffer in a separate call");
+        if (plane_stride < (int64_t)(x1 - x0)) return fail(ctx, RT_ERR_BAD_ARG, "row pitch smaller than the slab width");
+    } else if (plane_stride < (int64_t)(x1 - x0) * ctx->h) return fail(ctx, RT_ERR_BAD_ARG, "plane_stride smaller than the slab");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return launch(ctx, params, x0, x1, d_u8, d_f32, plane_stride, stream ? (hipStream_t)stream : ctx->stream);
 }
@@ -399,7 +402,10 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
     const size_t npx = (size_t)(x1 - x0) * ctx->h;
     if (out_u8 && (rc = ensure(ctx, ctx->u8, 3 * npx)) != RT_OK) return rc;
     if (out_f32 && (rc = ensure(ctx, ctx->f32, 3 * npx * sizeof(float))) != RT_OK) return rc;
-    rc = launch(ctx, params, x0, x1, out_u8 ? ctx->u8.p : nullptr, out_f32 ? ctx->f32.p : nullptr, (int64_t)npx, ctx->stream);
+    if ((params->flags & RT_FLAG_U8_HWC) && out_f32)
+        return fail(ctx, RT_ERR_BAD_ARG, "RT_FLAG_U8_HWC: request the uint8 image and the float32 buffer in separate calls");
+    rc = launch(ctx, params, x0, x1, out_u8 ? ctx->u8.p : nullptr, out_f32 ? ctx->f32.p : nullptr,
+                (params->flags & RT_FLAG_U8_HWC) ? (int64_t)(x1 - x0) : (int64_t)npx, ctx->stream);
     if (rc != RT_OK) return rc;
     if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8, ctx->u8.p, 3 * npx, hipMemcpyDeviceToHost, ctx->stream));
     if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32, ctx->f32.p, 3 * npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

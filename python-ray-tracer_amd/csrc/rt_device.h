@@ -74,7 +74,8 @@ struct KParams {
     int NC, pad2;              // sphere clusters (0 = flat)
     int aa, u8_rgb, tiles_y, ntiles;
     int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
-    unsigned seed, pad0;       // jitter hash seed (stochastic AA)
+    unsigned seed;             // jitter hash seed (stochastic AA)
+    int u8_hwc;                // uint8 frame interleaved as [y][x][3] (an image), row pitch = plane_stride pixels
     float extent2, pad1;       // max squared distance of camera / lights / sphere surfaces from the world origin
     double px, y0, dy, z0, dz;
     double cam_o[3];
@@ -810,9 +811,16 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
     if (off >= 0) {
         if (p.out_u8) {                                                       // kernels.py:69-73, common.py:60-63
             const uint8_t r8 = clip_color(R), g8 = clip_color(G), b8 = clip_color(B);
-            p.out_u8[off] = r8;
-            p.out_u8[p.plane_stride + off] = p.u8_rgb ? g8 : b8;
-            p.out_u8[2 * p.plane_stride + off] = p.u8_rgb ? b8 : g8;
+            const uint8_t c1 = p.u8_rgb ? g8 : b8, c2 = p.u8_rgb ? b8 : g8;
+            if (p.u8_hwc) {                                                   // image layout: row y, column x, 3 bytes
+                const long long xr = off / p.h, yy = off - xr * p.h;
+                uint8_t *px = p.out_u8 + (yy * p.plane_stride + xr) * 3;
+                px[0] = r8; px[1] = c1; px[2] = c2;
+            } else {
+                p.out_u8[off] = r8;
+                p.out_u8[p.plane_stride + off] = c1;
+                p.out_u8[2 * p.plane_stride + off] = c2;
+            }
         }
         if (p.out_f32) {
             p.out_f32[off] = (float)R;

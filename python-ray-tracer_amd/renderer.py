@@ -118,7 +118,8 @@ class Renderer:
         x1 = (self.w or 0) if x1 is None else int(x1)
         p = self.params(amb, lamb, refl, depth, aa, flags, refl_pow, spp, seed)
         n = max(x1 - int(x0), 0)     # a bad range still goes to the library, which reports it
-        out8 = np.empty((3, n, self.h or 0), np.uint8) if u8 else None
+        hwc = bool(int(flags) & L.RT_FLAG_U8_HWC)
+        out8 = np.empty(((self.h or 0), n, 3) if hwc else (3, n, self.h or 0), np.uint8) if u8 else None
         out32 = np.empty((3, n, self.h or 0), np.float32) if f32 else None
         self._check(self._lib.rt_render(self._ctx, C.byref(p), int(x0), x1,
                                         out8.ctypes.data if u8 else None, out32.ctypes.data if f32 else None))

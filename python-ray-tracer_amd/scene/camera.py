@@ -22,11 +22,12 @@ class PixelGrid(np.ndarray):
 
 
 class Camera:
-    def __init__(self, resolution, position, euler, fov=45.0):
+    def __init__(self, resolution, position, euler, fov=45.0, true_aspect=False):
         self.resolution = resolution
         self._position = position
         self.rotation = euler_rotation(euler[0], euler[1], euler[2])
         self.field_of_view = fov
+        self.true_aspect = true_aspect      # False: the reference's AR = int(w/h); True: AR = w/h
 
     @property
     def position(self):
@@ -34,9 +35,10 @@ class Camera:
 
     def raygen(self):
         """(px, y0, dy, z0, dz).  AR = int(width/height) truncates as the reference does
-        (camera.py:22): 1 for 16:9, 0 for portrait frames."""
+        (camera.py:22): 1 for 16:9, 0 for portrait frames.  true_aspect=True uses w/h instead
+        (an undistorted 16:9 image; not what the reference renders)."""
         width, height = self.resolution
-        ar = int(width / height)
+        ar = width / height if self.true_aspect else int(width / height)
         px = float(1 / np.tan(np.radians(self.field_of_view) / 2))
         dy = (-ar - ar) / float(width - 1) if width > 1 else 1.0
         dz = (-1 - 1) / float(height - 1) if height > 1 else 1.0

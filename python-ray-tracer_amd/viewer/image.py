@@ -17,5 +17,9 @@ def frame_to_hwc(x, undo_swap=False):
 
 
 def convert_array_to_image(x, undo_swap=False):
+    """(3,w,h) frame -> PIL image; an (h,w,3) array (rendered with RT_FLAG_U8_HWC on the device) is used as is."""
     from PIL import Image
+    x = np.asarray(x)
+    if x.ndim == 3 and x.shape[2] == 3 and x.shape[0] != 3:
+        return Image.fromarray(np.ascontiguousarray(x.astype(np.uint8)))
     return Image.fromarray(frame_to_hwc(x, undo_swap))

@@ -254,3 +254,22 @@ def test_tile_stats(renderer):
     finally:
         renderer.set_tile_stats(None)
         renderer.free(d)
+
+
+def test_u8_hwc_image_layout(renderer):
+    """RT_FLAG_U8_HWC: the device writes the interleaved (h,w,3) image the reference's viewer builds on the host."""
+    from python_ray_tracer_amd import _lib as L
+    from python_ray_tracer_amd.viewer import frame_to_hwc
+    g = load_frame("odd_37x29")
+    _setup(renderer, g)
+    planar, _ = renderer.render(0.0, 0.6, 0.3, int(g["depth"]), 0, u8=True, f32=False, refl_pow=g["refl_pow"])
+    img, _ = renderer.render(0.0, 0.6, 0.3, int(g["depth"]), 0, u8=True, f32=False, refl_pow=g["refl_pow"], flags=L.RT_FLAG_U8_HWC)
+    assert img.shape == (29, 37, 3) and np.array_equal(img, frame_to_hwc(planar))
+    rgb, _ = renderer.render(0.0, 0.6, 0.3, int(g["depth"]), 0, u8=True, f32=False, refl_pow=g["refl_pow"],
+                             flags=L.RT_FLAG_U8_HWC | L.RT_FLAG_U8_RGB)
+    assert np.array_equal(rgb, frame_to_hwc(planar, undo_swap=True))
+    part, _ = renderer.render(0.0, 0.6, 0.3, int(g["depth"]), 0, u8=True, f32=False, refl_pow=g["refl_pow"], flags=L.RT_FLAG_U8_HWC, x0=8, x1=24)
+    assert np.array_equal(part, img[:, 8:24])
+    import python_ray_tracer_amd as pkg
+    with pytest.raises(pkg.RenderError):
+        renderer.render(0.0, 0.6, 0.3, 1, 0, u8=True, f32=True, flags=L.RT_FLAG_U8_HWC)

@@ -71,3 +71,11 @@ def test_workloads_match_golden_scenes():
     wl, g = workloads.build("c5_7680x4320_s256_d8_spp4"), load_frame("c5_s256_d8_spp4_sub96")
     assert (wl["aa"], wl["spp"], wl["seed"]) == (int(g["aa"]), int(g["spp"]), int(g["seed"]))
     assert wl["spheres"].tobytes() == g["spheres"].tobytes()
+
+
+def test_true_aspect_option():
+    ref = Camera((1920, 1080), [-2, 0, 2.0], [0, -30, 0]).raygen()
+    tru = Camera((1920, 1080), [-2, 0, 2.0], [0, -30, 0], true_aspect=True).raygen()
+    assert ref[1] == 1.0 and abs(tru[1] - 16 / 9) < 1e-15 and tru[2] == (-2 * tru[1]) / 1919.0 and ref[3:] == tru[3:]
+    g = Camera((32, 18), [-2, 0, 2.0], [0, -30, 0], true_aspect=True).generate_pixel_locations()
+    assert g[1, 0, 0] == 32 / 18 and g[1, -1, 0] == -g[1, 0, 0] and g.raygen is not None
