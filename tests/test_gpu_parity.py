@@ -273,3 +273,42 @@ def test_u8_hwc_image_layout(renderer):
     import python_ray_tracer_amd as pkg
     with pytest.raises(pkg.RenderError):
         renderer.render(0.0, 0.6, 0.3, 1, 0, u8=True, f32=True, flags=L.RT_FLAG_U8_HWC)
+
+
+@pytest.mark.parametrize("S,Ln,P", [(1024, 3, 1), (700, 64, 64), (97, 0, 0)])
+def test_scene_size_limits_vs_oracle(renderer, oracle, S, Ln, P):
+    """RT_MAX_SPHERES / RT_MAX_LIGHTS / RT_MAX_PLANES: LDS images beyond 64 KiB, no room for the anchored cull
+    table (origin-form culling with clusters only), many lights and planes — bit-exact against the oracle."""
+    rng = np.random.default_rng(S + Ln)
+    sp = np.zeros((7, S), np.float32)
+    sp[0:3] = rng.uniform(-6, 8, (3, S)); sp[3] = rng.uniform(0.05, 0.4, S); sp[4:7] = rng.integers(0, 256, (3, S))
+    li = rng.uniform(-6, 8, (3, Ln)).astype(np.float32)
+    if Ln:
+        li[2] = np.abs(li[2]) + 2.0
+    pl = np.zeros((9, P), np.float32)
+    if P:
+        pl[0:3] = rng.uniform(-3, 3, (3, P)); pl[2] -= 6.0
+        n = rng.normal(size=(3, P)); n[2] = np.abs(n[2]) + 1.0
+        pl[3:6] = n / np.linalg.norm(n, axis=0, keepdims=True); pl[6:9] = rng.integers(0, 256, (3, P))
+    from python_ray_tracer_amd.scene import Camera
+    w, h = 48, 40
+    cam = Camera((w, h), [-3.0, 0.5, 2.5], [3, -25, 4])
+    rg = cam.raygen()
+    renderer.set_scene(sp, li, pl); renderer.set_camera(cam.position, cam.rotation); renderer.set_raygen(w, h, *rg)
+    for aa in (0, 1):
+        u8, f32 = renderer.render(0.05, 0.5, 0.4, 3, aa, u8=True, f32=True)
+        ref = oracle.render(w, h, cam.position, cam.rotation, sp, li, pl, 0.05, 0.5, 0.4, 3, aa, raygen=rg, want=("u8", "f32"))
+        assert np.array_equal(u8, ref["u8"]), f"aa={aa}: {(u8 != ref['u8']).any(axis=0).sum()} px differ"
+        assert np.array_equal(f32, ref["f32"])
+    import python_ray_tracer_amd as pkg
+    with pytest.raises(pkg.RenderError):
+        renderer.set_scene(np.zeros((7, 1025), np.float32), li, pl)
+
+
+def test_max_depth(renderer, oracle):
+    g = load_frame("fov70_48")
+    w, h, rg = _setup(renderer, g)
+    u8, f32 = renderer.render(0.02, 0.6, 0.6, 16, 0, u8=True, f32=True)
+    ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.02, 0.6, 0.6, 16, 0,
+                        raygen=rg, want=("u8", "f32"))
+    assert np.array_equal(u8, ref["u8"]) and np.array_equal(f32, ref["f32"])
