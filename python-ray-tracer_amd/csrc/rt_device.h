@@ -28,20 +28,26 @@
 
 #pragma clang fp contract(off)
 
+// Build-time knobs (A/B builds for tools/ab_bench.py); the defaults are the measured best on MI355X:
+//   RT_PREFILTER        float32 cull in front of the float64 sphere tests            (C2 -10 %, C5 -50 %)
+//   RT_FAST_NORMALIZE   shared-reciprocal normalize instead of sqrt + three divisions (C2 -7 %)
+//   RT_WAVES_PER_WG     tiles (wavefronts) per workgroup: 4 beats 1, 2, 6 and 8 by 10-75 %
+//   RT_CLUSTER_MIN      sphere count above which the scene is stored in clusters of 8
+//   RT_W_PARK, RT_W_AAPARK  waves/SIMD the LDS-parked variants are compiled for
 #ifndef RT_PREFILTER
 #define RT_PREFILTER 1
 #endif
 #ifndef RT_FAST_NORMALIZE
 #define RT_FAST_NORMALIZE 1
 #endif
-#ifndef RT_ABLATE
-#define RT_ABLATE 0   // diagnostic builds only: 1 = no shadow queries, 2 = cheap shading normalise, 3 = no sphere loop in closest hit
-#endif
 
 namespace rt {
 
 constexpr int TILE = 8;            // 8x8 pixels per wavefront
-constexpr int WAVES_PER_WG = 4;
+#ifndef RT_WAVES_PER_WG
+#define RT_WAVES_PER_WG 4
+#endif
+constexpr int WAVES_PER_WG = RT_WAVES_PER_WG;
 constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 constexpr int SPH_STRIDE = 8;      // doubles per sphere record: cx,cy,cz,r2, R,G,B, caller's index
 constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, R,G,B, axis code (0 general, +-1/2/3 = +-e_x/y/z)
@@ -54,10 +60,6 @@ constexpr int CLUSTER = 8;         // spheres per cluster
 constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, w+margin (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
-#ifndef RT_CULL_UNROLL
-#define RT_CULL_UNROLL 4
-#endif
-constexpr int CULL_UNROLL = RT_CULL_UNROLL;   // spheres culled per straight-line group (ILP vs registers)
 
 struct KParams {
     const double *scene;       // packed records: S spheres, then P planes, then L lights
@@ -92,13 +94,8 @@ __device__ __forceinline__ double dot3(const V3 &a, const V3 &b) { return a.x * 
 // common.py:28-32 — sqrt and three true divisions, as the compiler lowers them (correctly rounded).
 __device__ __forceinline__ V3 normalize3_generic(const V3 &v)
 {
-#if RT_ABLATE == 2
-    double n = 1.0 / (float)(v.x * v.x + v.y * v.y + v.z * v.z);   // diagnostic: wrong on purpose, cheap
-    return V3{v.x * n, v.y * n, v.z * n};
-#else
     double n = __builtin_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
     return V3{v.x / n, v.y / n, v.z / n};
-#endif
 }
 
 // The same normalize with the work the three divisions have in common done once.  The AMDGPU backend lowers
@@ -115,7 +112,7 @@ __device__ __forceinline__ V3 normalize3_generic(const V3 &v)
 // with seeds 16x less accurate than v_rsq_f64 / v_rcp_f64.
 __device__ __forceinline__ V3 normalize3(const V3 &v)
 {
-#if RT_ABLATE == 2 || RT_FAST_NORMALIZE == 0
+#if RT_FAST_NORMALIZE == 0
     return normalize3_generic(v);
 #else
     const double nn = v.x * v.x + v.y * v.y + v.z * v.z;
@@ -411,7 +408,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #endif
     double bestn = __builtin_inf(), borig = 0.0;
     int bidx = -1;
-    for (int k0 = 0; k0 < (RT_ABLATE == 3 ? 0 : S); k0 += 64) {
+    for (int k0 = 0; k0 < S; k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
@@ -581,11 +578,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             // :92-102 — the shadow query's answer is only used when k > 0; it has no other effect,
             // so lanes with k <= 0 (light behind the surface) do not ask.
             if (k > 0.0) {
-#if RT_ABLATE == 1
-                const bool occluded = false;
-#else
                 const bool occluded = any_hit(lds, p, Pt, Ld, 1 + m, self);
-#endif
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
