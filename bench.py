@@ -191,6 +191,15 @@ def main():
                          "note": "float64 VALU-bound by construction (about 15 B and ~2 kflop per pixel): the HBM fraction "
                                  "is reported because BASELINE.json's north_star asks for it, not because HBM limits this kernel"},
         }
+        # The bound that actually limits this kernel: VALU instruction issue.  Static per-launch counts from the
+        # rocprofv3 op-mix pass (profiles/valu_r01.json); achieved = float64 FLOP / kernel time vs the fp64 vector peak.
+        vpath = os.path.join(REPO, "profiles", "valu_r01.json")
+        if world == 1 and name == workloads.HEADLINE and os.path.exists(vpath):
+            v = json.load(open(vpath))
+            out["valu"] = {"fp64_flop_per_launch": v["fp64_flop_per_launch"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"],
+                           "achieved_fp64_tflops": round(v["fp64_flop_per_launch"] / (kernel_ms_max * 1e-3) / 1e12, 3),
+                           "peak_fp64_vector_tflops": 78.6, "frac": round(v["fp64_flop_per_launch"] / (kernel_ms_max * 1e-3) / 78.6e12, 4),
+                           "note": v["note"]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, rays_per_frame)
         print(json.dumps(out), flush=True)
