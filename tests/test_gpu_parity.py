@@ -312,3 +312,21 @@ def test_max_depth(renderer, oracle):
     ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.02, 0.6, 0.6, 16, 0,
                         raygen=rg, want=("u8", "f32"))
     assert np.array_equal(u8, ref["u8"]) and np.array_equal(f32, ref["f32"])
+
+
+@pytest.mark.parametrize("case", ["aa_48_d2", "stoch_48_spp4"])
+def test_column_slabs_with_antialiasing(renderer, case):
+    """Slab tiling must not change AA results: the 9-tap mode reads neighbours across the slab edge, the
+    stochastic mode hashes absolute pixel coordinates."""
+    from python_ray_tracer_amd.distributed import slab_bounds
+    g = load_frame(case)
+    w, h, _ = _setup(renderer, g)
+    full8, full32 = _render(renderer, g)
+    for n in (2, 3):
+        parts = [_render(renderer, g, x0=a, x1=b) for a, b in (slab_bounds(w, n, r) for r in range(n))]
+        assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), full8)
+        assert np.array_equal(np.concatenate([p[1] for p in parts], axis=1), full32)
+    _setup(renderer, g, explicit_grid=(case == "aa_48_d2"))
+    if case == "aa_48_d2":          # explicit pixel_loc + slabs + 9 taps
+        part8, _ = _render(renderer, g, x0=16, x1=32)
+        assert np.array_equal(part8, full8[:, 16:32])
