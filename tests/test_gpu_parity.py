@@ -3,6 +3,8 @@ against (1) the committed golden vectors produced by the reference's own Python 
 oracle on the same inputs.  Bars: uint8 frame bit-exact; float32 pre-clip colour within 1e-5 abs of
 the reference's float64 value on the displayable range [0,255] (north_star tolerance) — and, since
 the kernel evaluates the same IEEE float64 operations, bit-equal to the oracle's float32 rounding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -330,3 +332,30 @@ def test_column_slabs_with_antialiasing(renderer, case):
     if case == "aa_48_d2":          # explicit pixel_loc + slabs + 9 taps
         part8, _ = _render(renderer, g, x0=16, x1=32)
         assert np.array_equal(part8, full8[:, 16:32])
+
+
+def test_c_abi_example_without_python(tmp_path, renderer):
+    """examples/render_c_abi.c links the library from plain C (gcc), renders and writes an image; the same inputs
+    through the Python host must give the same bytes."""
+    import math, subprocess
+    from conftest import REPO
+    exe, out = str(tmp_path / "render_c_abi"), str(tmp_path / "img.ppm")
+    libdir = os.path.join(REPO, "python-ray-tracer_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "render_c_abi.c"),
+                           "-L", libdir, "-lmi355rt", "-lm", f"-Wl,-rpath,{libdir}", "-o", exe])
+    log = subprocess.check_output([exe, out], text=True)
+    assert "wrote" in log
+    raw = open(out, "rb").read()
+    assert raw.startswith(b"P6\n512 512\n255\n")
+    img = np.frombuffer(raw[len(b"P6\n512 512\n255\n"):], np.uint8).reshape(512, 512, 3)
+    from python_ray_tracer_amd.scene import Scene
+    from python_ray_tracer_amd import _lib as L
+    sp, li, pl = Scene.default_scene().generate_scene()
+    th = -30.0 * math.pi / 180.0
+    c, s = math.cos(th), math.sin(th)
+    renderer.set_scene(sp, li, pl)
+    renderer.set_camera([-2.0, 0.0, 2.0], [c, 0, -s, 0, 1, 0, s, 0, c])
+    renderer.set_raygen(512, 512, 1.0 / math.tan((45.0 * math.pi / 180.0) / 2.0), 1.0, -2.0 / 511.0, 1.0, -2.0 / 511.0)
+    ref, _ = renderer.render(0.0, 0.6, 0.3, 2, 1, u8=True, f32=False, flags=L.RT_FLAG_U8_HWC | L.RT_FLAG_U8_RGB,
+                             refl_pow=[math.pow(0.3, i + 1) for i in range(2)])
+    assert np.array_equal(img, ref)
