@@ -202,6 +202,9 @@ def main():
             out["valu"] = {"fp64_flop_per_launch": v["fp64_flop_per_launch"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"],
                            "achieved_fp64_tflops": round(v["fp64_flop_per_launch"] / (kernel_ms_max * 1e-3) / 1e12, 3),
                            "peak_fp64_vector_tflops": 78.6, "frac": round(v["fp64_flop_per_launch"] / (kernel_ms_max * 1e-3) / 78.6e12, 4),
+                           # every VALU wave-instruction occupies its SIMD for 4 cycles (64 lanes over 16): 1024 SIMDs at 2.4 GHz
+                           "issue_bound_ms": round(v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) * 1e3, 5),
+                           "issue_frac": round(v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) / (kernel_ms_max * 1e-3), 4),
                            "note": v["note"]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, rays_per_frame)

@@ -67,7 +67,10 @@ typedef enum rt_status {
                                 pixels (x1-x0 for a compact slab); uint8 output only */
 #define RT_FLAG_NO_FEEDBACK 4 /* dispatch tiles in plain order; by default a launch dispatches its workgroups
                                 longest-first using the per-tile cycles the previous launch of the same
-                                geometry recorded (same pixels either way) */
+                                geometry recorded (same pixels either way).  Once two consecutive launches
+                                have measured the same scene, camera, grid, range, depth and AA mode the
+                                order is kept and measuring stops until an rt_set_* call or another
+                                range/depth/mode/stream starts it again */
 
 typedef struct rt_ctx rt_ctx;
 

@@ -47,7 +47,10 @@ struct rt_ctx {
         Buf hist, slot, order;        // cost histogram, per-block (bucket, rank), dispatch order
         long long key = -1;           // launch geometry `order` was built for (-1: none)
         hipStream_t stream = nullptr; // stream it was built on
+        unsigned long long epoch = 0; // ctx->epoch the costs were measured under
+        int builds = 0;               // consecutive builds under that key and epoch
     } fb;
+    unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
     std::string err;
 };
 
@@ -149,9 +152,18 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     // order built from the previous launch if that ran on the same stream with the same geometry.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
-    const long long key = ((long long)x0 << 42) ^ ((long long)x1 << 21) ^ (long long)ctx->h ^ ((long long)k.aa << 62);
+    const long long key = ((long long)x0 << 42) ^ ((long long)x1 << 21) ^ (long long)ctx->h ^ ((long long)k.aa << 62)
+                          ^ ((long long)k.depth << 56) ^ ((long long)(k.aa == RT_AA_STOCHASTIC ? k.spp : 0) << 48);
     rt_ctx::Feedback &f = ctx->fb;
-    if (feedback) {
+    // Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile
+    // order, once from longest-first order): the costs are the same again, so the launch neither measures nor
+    // rebuilds -- it just dispatches in that order.  Any rt_set_* call, another range/depth/AA mode or another
+    // stream starts measuring again.
+    const bool settled = feedback && f.key == key && f.stream == stream && f.epoch == ctx->epoch && f.builds >= 2
+                         && f.order.cap >= (size_t)grid * sizeof(unsigned);
+    if (settled) {
+        k.order = (const unsigned *)f.order.p;
+    } else if (feedback) {
         if (!f.hist.p) {
             int rc0 = ensure(ctx, f.hist, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned));
             if (rc0 != RT_OK) return rc0;
@@ -167,11 +179,15 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     }
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(rt::WG_THREADS), args, lds, stream));
-    if (feedback) {
+    if (settled) {
+        // order stays as it is
+    } else if (feedback) {
         hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
                            (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid);
+        f.builds = (f.key == key && f.stream == stream && f.epoch == ctx->epoch) ? f.builds + 1 : 1;
         f.key = key;
         f.stream = stream;
+        f.epoch = ctx->epoch;
     } else {
         f.key = -1;
     }
@@ -338,6 +354,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
     ctx->scene_extent2 = ext2;
     ctx->S = S; ctx->P = P; ctx->L = L; ctx->NC = nclusters;
     ctx->have_scene = true;
+    ctx->epoch++;
     return RT_OK;
 }
 
@@ -348,6 +365,7 @@ int rt_set_camera(rt_ctx *ctx, const double origin[3], const double rotation[9])
     std::memcpy(ctx->cam_o, origin, sizeof ctx->cam_o);
     std::memcpy(ctx->cam_R, rotation, sizeof ctx->cam_R);
     ctx->have_cam = true;
+    ctx->epoch++;
     return RT_OK;
 }
 
@@ -358,6 +376,7 @@ int rt_set_raygen(rt_ctx *ctx, int w, int h, double px, double y0, double dy, do
     ctx->w = w; ctx->h = h; ctx->px = px; ctx->y0 = y0; ctx->dy = dy; ctx->z0 = z0; ctx->dz = dz;
     ctx->explicit_grid = false;
     ctx->have_grid = true;
+    ctx->epoch++;
     return RT_OK;
 }
 
@@ -375,6 +394,7 @@ int rt_set_pixel_loc(rt_ctx *ctx, const double *pixel_loc, int w, int h)
     ctx->w = w; ctx->h = h;
     ctx->explicit_grid = true;
     ctx->have_grid = true;
+    ctx->epoch++;
     return RT_OK;
 }
 

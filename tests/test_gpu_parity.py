@@ -239,6 +239,20 @@ def test_feedback_dispatch_order_never_changes_pixels(renderer):
     assert np.array_equal(a8, g["frame_u8"][:, 8:72]) and np.array_equal(b8, a8)
     u8, _ = _render(renderer, g)
     assert np.array_equal(u8, g["frame_u8"])
+    # Settled order (third launch on: no measuring, no rebuild), then another golden's scene
+    # (another scene and depth: stale order on the first frame after it, measuring again) and back.
+    g2 = load_frame("c1_128")
+    for _ in range(4):
+        u8, _ = _render(renderer, g)
+        assert np.array_equal(u8, g["frame_u8"])
+    _setup(renderer, g2)
+    for _ in range(4):
+        u8, _ = _render(renderer, g2)
+        assert np.array_equal(u8, g2["frame_u8"])
+    _setup(renderer, g)
+    for _ in range(4):
+        u8, f32b = _render(renderer, g)
+        assert np.array_equal(u8, g["frame_u8"]) and np.array_equal(f32b, f32)
 
 
 def test_tile_stats(renderer):
