@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 #define RT_MAX_DEPTH 16      /* entries of rt_params.refl_pow (reflection bounces) */
 #define RT_MAX_SPHERES 1024  /* scene limits: the packed scene must fit one workgroup's LDS */
 #define RT_MAX_PLANES 64
@@ -159,6 +159,14 @@ int rt_memcpy_d2h(rt_ctx *ctx, void *dst_host, const void *src_device, size_t by
 /* Block until everything queued on the context's stream is done (the implicit sync of
  * copy_to_host, main.py:51). */
 int rt_sync(rt_ctx *ctx);
+
+/* Extra streams for callers that do not link HIP themselves: frames of a sequence can be queued alternately on two
+ * or more streams (each into its own output buffers) so that one frame's last workgroups overlap the next frame's
+ * first — the reference launches one frame and waits (main.py:41-51).  The handle is a hipStream_t; any
+ * hipStream_t of the context's device is equally valid wherever this header takes a `stream`. */
+int rt_stream_create(rt_ctx *ctx, void **stream);
+int rt_stream_destroy(rt_ctx *ctx, void *stream);
+int rt_stream_sync(rt_ctx *ctx, void *stream);   /* NULL = context stream */
 
 /* hipEvent pair on `stream` (NULL = context stream) around whatever is launched in between;
  * rt_timer_end synchronises on the second event and returns elapsed milliseconds. */

@@ -49,6 +49,9 @@ struct rt_ctx {
         hipStream_t stream = nullptr; // stream it was built on
         unsigned long long epoch = 0; // ctx->epoch the costs were measured under
         int builds = 0;               // consecutive builds under that key and epoch
+        hipEvent_t done = nullptr;    // recorded behind every order kernel
+        std::vector<std::pair<hipStream_t, hipEvent_t>> readers;   // other streams dispatching in the settled order
+        std::vector<hipEvent_t> spare;
     } fb;
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
     std::string err;
@@ -149,7 +152,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     }
     const unsigned grid = (unsigned)((k.ntiles + rt::WAVES_PER_WG - 1) / rt::WAVES_PER_WG);
     // Scheduler feedback (longest-first dispatch): a launch files its tile blocks by cost and dispatches in the
-    // order built from the previous launch if that ran on the same stream with the same geometry.
+    // order built from the previous measured launch of the same range, depth and AA mode.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
     const long long key = ((long long)x0 << 42) ^ ((long long)x1 << 21) ^ (long long)ctx->h ^ ((long long)k.aa << 62)
@@ -157,13 +160,40 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     rt_ctx::Feedback &f = ctx->fb;
     // Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile
     // order, once from longest-first order): the costs are the same again, so the launch neither measures nor
-    // rebuilds -- it just dispatches in that order.  Any rt_set_* call, another range/depth/AA mode or another
-    // stream starts measuring again.
-    const bool settled = feedback && f.key == key && f.stream == stream && f.epoch == ctx->epoch && f.builds >= 2
+    // rebuilds -- it just dispatches in that order, on any stream (frames of a static scene can be pipelined
+    // over several streams).  Any rt_set_* call or another range/depth/AA mode starts measuring again.
+    const bool settled = feedback && f.key == key && f.epoch == ctx->epoch && f.builds >= 2
                          && f.order.cap >= (size_t)grid * sizeof(unsigned);
+    // The feedback buffers belong to one stream at a time.  A launch on another stream measures only if the
+    // owner's last measuring launch has completed (it then takes the buffers over); otherwise it renders in
+    // plain order and leaves them alone.
+    bool measure = false;
     if (settled) {
         k.order = (const unsigned *)f.order.p;
+        if (stream != f.stream) {
+            bool known = false;
+            for (auto &r : f.readers) known = known || r.first == stream;
+            if (!known) {                                      // first settled launch of this stream: order complete?
+                hipEvent_t ev = nullptr;
+                if (!f.spare.empty()) { ev = f.spare.back(); f.spare.pop_back(); }
+                else RT_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                f.readers.emplace_back(stream, ev);
+                RT_HIP(ctx, hipStreamWaitEvent(stream, f.done, 0));
+            }
+        }
     } else if (feedback) {
+        measure = f.key == -1 || stream == f.stream || hipEventQuery(f.done) == hipSuccess;
+        (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
+    }
+    if (measure) {
+        for (auto &r : f.readers) {                            // settled launches elsewhere may still read `order`
+            if (r.first != stream) {
+                RT_HIP(ctx, hipEventRecord(r.second, r.first));
+                RT_HIP(ctx, hipStreamWaitEvent(stream, r.second, 0));
+            }
+            f.spare.push_back(r.second);
+        }
+        f.readers.clear();
         if (!f.hist.p) {
             int rc0 = ensure(ctx, f.hist, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned));
             if (rc0 != RT_OK) return rc0;
@@ -175,21 +205,18 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         if (rc != RT_OK) return rc;
         k.hist = (unsigned *)f.hist.p;
         k.slot = (unsigned *)f.slot.p;
-        k.order = (f.key == key && f.stream == stream) ? (const unsigned *)f.order.p : nullptr;
+        k.order = (f.key == key) ? (const unsigned *)f.order.p : nullptr;
     }
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(rt::WG_THREADS), args, lds, stream));
-    if (settled) {
-        // order stays as it is
-    } else if (feedback) {
+    if (measure) {
         hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
                            (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid);
-        f.builds = (f.key == key && f.stream == stream && f.epoch == ctx->epoch) ? f.builds + 1 : 1;
+        RT_HIP(ctx, hipEventRecord(f.done, stream));
+        f.builds = (f.key == key && f.epoch == ctx->epoch) ? f.builds + 1 : 1;
         f.key = key;
         f.stream = stream;
         f.epoch = ctx->epoch;
-    } else {
-        f.key = -1;
     }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -225,7 +252,8 @@ int rt_create(rt_ctx **out, int device)
     ctx->device = device;
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+        (s = hipEventCreateWithFlags(&ctx->fb.done, hipEventDisableTiming)) != hipSuccess) {
         std::string m = std::string("context setup: ") + hipGetErrorString(s);
         delete ctx;
         return fail(nullptr, RT_ERR_HIP, m);
@@ -241,6 +269,9 @@ int rt_destroy(rt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->fb.hist, &ctx->fb.slot, &ctx->fb.order})
         if (b->p) (void)hipFree(b->p);
+    for (auto &r : ctx->fb.readers) (void)hipEventDestroy(r.second);
+    for (hipEvent_t e : ctx->fb.spare) (void)hipEventDestroy(e);
+    if (ctx->fb.done) (void)hipEventDestroy(ctx->fb.done);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -477,6 +508,43 @@ int rt_sync(rt_ctx *ctx)
     if (!ctx) return RT_ERR_BAD_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_stream_create(rt_ctx *ctx, void **stream)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!stream) return fail(ctx, RT_ERR_BAD_ARG, "stream out-pointer is NULL");
+    *stream = nullptr;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    RT_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return RT_OK;
+}
+
+int rt_stream_destroy(rt_ctx *ctx, void *stream)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!stream) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    // the scheduler feedback may remember this stream as owner or reader: forget it
+    rt_ctx::Feedback &f = ctx->fb;
+    for (size_t i = 0; i < f.readers.size();) {
+        if (f.readers[i].first == (hipStream_t)stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }
+        else ++i;
+    }
+    if (f.stream == (hipStream_t)stream) f.stream = ctx->stream;   // its work is complete: anyone may take over
+    RT_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_stream_sync(rt_ctx *ctx, void *stream)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return RT_OK;
 }
 

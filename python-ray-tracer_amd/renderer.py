@@ -133,8 +133,23 @@ class Renderer:
                                                C.c_void_p(d_u8) if d_u8 else None, C.c_void_p(d_f32) if d_f32 else None,
                                                int(plane_stride), C.c_void_p(stream) if stream else None))
 
-    def sync(self):
-        self._check(self._lib.rt_sync(self._ctx))
+    def sync(self, stream=None):
+        """Wait for the context's stream, or for `stream` (a handle from stream_create / a hipStream_t address)."""
+        if stream:
+            self._check(self._lib.rt_stream_sync(self._ctx, C.c_void_p(stream)))
+        else:
+            self._check(self._lib.rt_sync(self._ctx))
+
+    def stream_create(self):
+        """An extra stream of this context's device: queue the frames of a sequence alternately on two or more
+        streams (each into its own output buffers) and one frame's tail overlaps the next frame's head."""
+        s = C.c_void_p()
+        self._check(self._lib.rt_stream_create(self._ctx, C.byref(s)))
+        return s.value
+
+    def stream_destroy(self, stream):
+        if stream and self._ctx.value:
+            self._check(self._lib.rt_stream_destroy(self._ctx, C.c_void_p(stream)))
 
     def timer_begin(self, stream=None):
         self._check(self._lib.rt_timer_begin(self._ctx, C.c_void_p(stream) if stream else None))

@@ -255,6 +255,51 @@ def test_feedback_dispatch_order_never_changes_pixels(renderer):
         assert np.array_equal(u8, g["frame_u8"]) and np.array_equal(f32b, f32)
 
 
+def test_frames_pipelined_over_streams(renderer):
+    """Frames of one context launched alternately on three streams, with scheduler feedback on: while the order is
+    being measured only the owning stream uses it, once settled every stream dispatches in it, and a setter call in
+    the middle of in-flight settled launches starts measuring again.  Every frame must be the reference frame."""
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+    streams = [renderer.stream_create() for _ in range(3)]
+    bufs = [renderer.malloc(3 * w * h) for _ in range(3)]
+    zero = np.zeros((3, w, h), np.uint8)
+
+    def burst(n):
+        for i in range(n):
+            renderer.render_device(p, 0, w, bufs[i % 3], None, w * h, stream=streams[i % 3])
+
+    def check():
+        for s in streams:
+            renderer.sync(s)
+        for b in bufs:
+            got = np.empty((3, w, h), np.uint8)
+            renderer.d2h(got, b)
+            assert np.array_equal(got, g["frame_u8"])
+            renderer.h2d(b, zero)
+    try:
+        for b in bufs:
+            renderer.h2d(b, zero)
+        burst(12)
+        renderer.set_camera(g["cam_origin"], g["cam_rot"])       # same camera, but the library must measure again
+        burst(9)
+        check()
+        renderer.set_camera(g["cam_origin"], g["cam_rot"])
+        burst(3)                                                  # measuring phase only: the other streams render in plain order
+        check()
+        burst(2)
+        renderer.stream_destroy(streams.pop(0))                   # the owner of the feedback buffers goes away
+        streams.append(renderer.stream_create())
+        burst(7)
+        check()
+    finally:
+        for s in streams:
+            renderer.stream_destroy(s)
+        for b in bufs:
+            renderer.free(b)
+
+
 def test_tile_stats(renderer):
     g = load_frame("default_128_d3")
     w, h, _ = _setup(renderer, g)
