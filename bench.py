@@ -4,8 +4,9 @@
 A step = one frame of BASELINE.json's headline configuration (configs[1]: 1920x1080, 8 spheres +
 1 plane, 3 lights, depth 3, no AA; synthetic scene = the reference's default scene + 2 spheres).
 With N > 1 ranks (one process per GPU, launched by torch.distributed.run) the SAME frame is cut into
-N column slabs, each rank renders its slab, and the uint8 frame is assembled on rank 0 by an RCCL
-gather — total work is fixed, so `scaling` is "strong".
+N column slabs, each rank renders its slab, and the uint8 frames are assembled on rank 0 by RCCL
+gathers (the slabs of several consecutive frames per gather) — total work is fixed, so `scaling` is "strong".
+Frames are queued round-robin on a few streams so that consecutive frames overlap.
 
 Inputs (scene, camera) are resident on the device before the timed region; outputs stay in HBM.
 Prints ONE JSON line on rank 0.
@@ -52,7 +53,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, help="one of python_ray_tracer_amd.workloads.CONFIGS")
-    ap.add_argument("--streams", type=int, default=2, help="streams the frames are queued on round-robin (1 = strictly serial)")
+    ap.add_argument("--streams", type=int, default=3, help="streams the frames are queued on round-robin (1 = strictly serial)")
+    ap.add_argument("--frames-per-gather", type=int, default=8, help="N > 1: frames whose slabs travel to rank 0 in one gather")
+    ap.add_argument("--force-gather", action="store_true", help="run the N > 1 exchange structure on one GPU (world-size-1 RCCL group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -86,44 +89,65 @@ def main():
     params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"])
     x0, x1 = slab_bounds(w, world, rank)
     ws = x1 - x0
-    # Frames are queued round-robin on `--streams` torch-owned, non-default streams (default 2), each slot with its
-    # own output buffers: one frame's last workgroups overlap the next frame's first, which a single in-order
-    # stream cannot do.  Every frame is rendered in full; `--streams 1` is the strictly serial variant.  (A NULL
-    # stream handed to rt_render_device would select the context's private stream instead.)
+    # Frames are queued round-robin on `--streams` torch-owned, non-default streams (default 3), each frame in flight
+    # with its own output buffers: one frame's last workgroups overlap the next frame's first, which a single
+    # in-order stream cannot do.  Every frame is rendered in full; `--streams 1` is the strictly serial variant.
+    # (A NULL stream handed to rt_render_device would select the context's private stream instead.)
+    # With N > 1 the uint8 slabs of `--frames-per-gather` consecutive frames travel to rank 0 in ONE gather (a
+    # collective costs tens of microseconds however small it is; a 240-column slab renders in less), issued on a
+    # separate stream, two exchanges in flight: batch i is gathered and assembled while batch i+1 renders.
     NS = max(1, a.streams)
     tstreams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     assert all(t.cuda_stream for t in tstreams), "expected non-default stream handles"
-    SLOTS = max(2, NS)                                  # with N > 1: frame i is gathered while frame i+1 renders
-    slabs_u8 = [torch.zeros((3, ws, h), dtype=torch.uint8, device=dev) for _ in range(SLOTS)]
-    slabs_f32 = [torch.zeros((3, ws, h), dtype=torch.float32, device=dev) for _ in range(SLOTS)]
-    gatherer = FrameGatherer(w, h, torch.uint8, dev, dist, dst=0, slots=SLOTS) if world > 1 else None
+    use_gather = world > 1 or a.force_gather
+    if a.force_gather and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+    F = max(1, a.frames_per_gather) if use_gather else 1
+    SLOTS = 2 if use_gather else NS                     # exchanges in flight / frames in flight
+    slabs_u8 = [torch.zeros((F, 3, ws, h), dtype=torch.uint8, device=dev) for _ in range(SLOTS)]
+    slabs_f32 = [torch.zeros((F, 3, ws, h), dtype=torch.float32, device=dev) for _ in range(SLOTS)]
+    comm = torch.cuda.Stream(device=dev) if use_gather else None
+    gatherer = FrameGatherer(w, h, torch.uint8, dev, dist, dst=0, slots=SLOTS, batch=F) if use_gather else None
     busy = [False] * SLOTS
     frame = None
 
-    def step(i):
+    def collect(s_):
         nonlocal frame
-        b = i % SLOTS
-        ts = tstreams[b % NS]
-        with torch.cuda.stream(ts):                     # the gather's stream dependencies follow torch's current stream
-            if gatherer is not None and busy[b]:        # the slab is reused: its gather must have completed
-                f = gatherer.finish(b)
-                frame = f if f is not None else frame
-                busy[b] = False
-            r.render_device(params, x0, x1, slabs_u8[b].data_ptr(), slabs_f32[b].data_ptr(), ws * h, ts.cuda_stream)
-            if gatherer is not None:
-                gatherer.submit(slabs_u8[b], b)
-                busy[b] = True
-            else:
-                frame = slabs_u8[b]
+        with torch.cuda.stream(comm):                   # the gather's stream dependencies follow torch's current stream
+            f = gatherer.finish(s_)
+            if f is not None:
+                frame = f if F == 1 else f[0]
+        busy[s_] = False
 
-    def drain():
+    def step(i, last):
         nonlocal frame
-        for b in range(SLOTS):
-            if gatherer is not None and busy[b]:
-                with torch.cuda.stream(tstreams[b % NS]):
-                    f = gatherer.finish(b)
-                frame = f if f is not None else frame
-                busy[b] = False
+        ts = tstreams[i % NS]
+        if not use_gather:
+            b = i % NS
+            r.render_device(params, x0, x1, slabs_u8[b].data_ptr(), slabs_f32[b].data_ptr(), ws * h, ts.cuda_stream)
+            frame = slabs_u8[b][0]
+            return
+        s_, j = (i // F) % SLOTS, i % F
+        if j == 0 and busy[s_]:                         # the slot's slabs are reused: its exchange must have completed
+            collect(s_)
+            ev = comm.record_event()
+            for t_ in tstreams:
+                t_.wait_event(ev)
+        r.render_device(params, x0, x1, slabs_u8[s_][j].data_ptr(), slabs_f32[s_][j].data_ptr(), ws * h, ts.cuda_stream)
+        if j == F - 1 or last:                          # the batch is complete (or the sequence ends): one gather
+            for t_ in tstreams:
+                comm.wait_event(t_.record_event())
+            with torch.cuda.stream(comm):
+                gatherer.submit(slabs_u8[s_], s_)
+            busy[s_] = True
+
+    def drain(n):                                       # n = frames queued since the last drain (oldest slot first)
+        if use_gather:
+            cur = ((n - 1) // F) % SLOTS if n else 0
+            for s_ in [(cur + 1 + k) % SLOTS for k in range(SLOTS)]:
+                if busy[s_]:
+                    collect(s_)
 
     def fence():
         torch.cuda.synchronize()
@@ -131,16 +155,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.cuda.stream(tstreams[0]):
+    for _ in range(2):                                  # setup, like the uploads above: the first two launches of a geometry
         r.render_device(params, x0, x1, slabs_u8[0].data_ptr(), slabs_f32[0].data_ptr(), ws * h, tstreams[0].cuda_stream)
-        r.render_device(params, x0, x1, slabs_u8[0].data_ptr(), slabs_f32[0].data_ptr(), ws * h, tstreams[0].cuda_stream)
-    torch.cuda.synchronize()                            # setup, like the uploads above: the first two launches of a geometry
-    for i in range(a.warmup):                           # measure tile costs and build the dispatch order
-        step(i)
-    drain()
+    torch.cuda.synchronize()                            # measure tile costs and build the dispatch order
+    for i in range(a.warmup):
+        step(i, i == a.warmup - 1)
+    drain(a.warmup)
     # One HIP event pair per launch stream around the whole timed region: elapsed / (launches on that stream) is
     # the mean duration of one launch as rocprofv3's kernel trace sees it (launches on one stream run back to back;
-    # with N > 1 it also holds whatever part of the gather does not overlap) — NS of them are in flight at a time.
+    # with N > 1 it also holds whatever waiting for a free slab costs) — NS of them are in flight at a time.
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     fence()
@@ -148,13 +171,13 @@ def main():
     for s_ in range(NS):
         ev0[s_].record(tstreams[s_])
     for i in range(a.steps):
-        step(i)
+        step(i, i == a.steps - 1)
     for s_ in range(NS):
         ev1[s_].record(tstreams[s_])
-    drain()                                             # every one of the K frames is assembled on rank 0
+    drain(a.steps)                                      # every one of the K frames is assembled on rank 0
     fence()
     dt = time.perf_counter() - t0
-    launches = [sum(1 for i in range(a.steps) if (i % SLOTS) % NS == s_) for s_ in range(NS)]
+    launches = [len(range(s_, a.steps, NS)) for s_ in range(NS)]
     spans = [ev0[s_].elapsed_time(ev1[s_]) / launches[s_] for s_ in range(NS) if launches[s_]]
     kernel_ms = sum(spans) / max(len(spans), 1)
 
@@ -196,7 +219,7 @@ def main():
                        "depth": wl["depth"], "aa": bool(wl["aa"]), "rays_per_frame": rays_per_frame,
                        "primary_rays_per_frame": w * h, "outputs": "uint8 (3,w,h) frame + float32 (3,w,h) pre-clip RGB",
                        "streams": NS,
-                       "parallelism": f"column slabs x{world}, frames queued round-robin on {NS} stream(s)" + (", one RCCL gather of the uint8 frame to rank 0 per step, overlapped with the next step's render" if world > 1 else "")},
+                       "parallelism": f"column slabs x{world}, frames queued round-robin on {NS} stream(s)" + (f", one RCCL gather of the uint8 slabs of {F} frames to rank 0 per {F} steps, overlapped with the next steps' renders" if use_gather else "")},
             "frame_ms": round(ms_per_step, 5), "frame_latency_ms": round(kernel_ms_max, 5),
             "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
             "frame_matches_reference_sha256": check,
@@ -226,7 +249,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, rays_per_frame)
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if world > 1 or a.force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

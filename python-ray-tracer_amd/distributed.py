@@ -27,13 +27,18 @@ class FrameGatherer:
     """Assembles per-rank slabs of shape (3, x1-x0, h) into (3,w,h) frames on rank `dst`.
 
     submit(slab, slot) starts the exchange for one frame (asynchronously where the backend allows) and
-    finish(slot) completes it and returns the frame on `dst` (None elsewhere).  `slots` frames may be in
-    flight; a slot's slab must not be overwritten between its submit() and finish()."""
+    finish(slot) completes it and returns the frame on `dst` (None elsewhere).  `slots` exchanges may be in
+    flight; a slot's slab must not be overwritten between its submit() and finish().
 
-    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2):
+    batch=F > 1 moves F frames per exchange: slabs are (F, 3, x1-x0, h), finish() returns (F, 3, w, h).  A
+    collective costs tens of microseconds however small it is, a slab of a 1080p frame renders in less, so a
+    sequence of frames is assembled F at a time (fewer, larger collectives)."""
+
+    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2, batch=1):
         import torch
         self.torch, self.dist, self.dst = torch, dist, dst
-        self.w, self.h = w, h
+        self.w, self.h, self.batch = w, h, int(batch)
+        assert self.batch >= 1
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.bounds = [slab_bounds(w, self.world, r) for r in range(self.world)]
         widths = {b - a for a, b in self.bounds}
@@ -42,28 +47,31 @@ class FrameGatherer:
         self.pending = [None] * slots
         self.frames = self.stage = None
         if self.rank == dst:
-            self.frames = [torch.empty((3, w, h), dtype=dtype, device=device) for _ in range(slots)]
+            self.frames = [torch.empty((self.batch, 3, w, h), dtype=dtype, device=device) for _ in range(slots)]
             if self.equal:
-                self.stage = [torch.empty((self.world, 3, self.ws, h), dtype=dtype, device=device) for _ in range(slots)]
+                self.stage = [torch.empty((self.world, self.batch, 3, self.ws, h), dtype=dtype, device=device) for _ in range(slots)]
 
     def submit(self, slab, slot):
         assert self.pending[slot] is None, "slot still in flight: call finish(slot) first"
-        assert tuple(slab.shape) == (3, self.ws, self.h) and slab.is_contiguous()
+        if self.batch == 1 and slab.dim() == 3:
+            slab = slab.unsqueeze(0)
+        assert tuple(slab.shape) == (self.batch, 3, self.ws, self.h) and slab.is_contiguous()
         dist, root = self.dist, self.rank == self.dst
         if self.equal:
             recv = [self.stage[slot][r] for r in range(self.world)] if root else None
             self.pending[slot] = ("gather", dist.gather(slab, recv, dst=self.dst, async_op=True))
             return
         reqs = []                                       # ragged: plane-wise straight into the frame
-        for c in range(3):
-            if root:
-                for r, (a, b) in enumerate(self.bounds):
-                    if r == self.dst:
-                        self.frames[slot][c, a:b].copy_(slab[c])
-                    elif b > a:
-                        reqs.append(dist.irecv(self.frames[slot][c, a:b], src=r))
-            elif self.ws:
-                reqs.append(dist.isend(slab[c], dst=self.dst))
+        for j in range(self.batch):
+            for c in range(3):
+                if root:
+                    for r, (a, b) in enumerate(self.bounds):
+                        if r == self.dst:
+                            self.frames[slot][j, c, a:b].copy_(slab[j, c])
+                        elif b > a:
+                            reqs.append(dist.irecv(self.frames[slot][j, c, a:b], src=r))
+                elif self.ws:
+                    reqs.append(dist.isend(slab[j, c], dst=self.dst))
         self.pending[slot] = ("p2p", reqs)
 
     def finish(self, slot):
@@ -74,11 +82,14 @@ class FrameGatherer:
             if self.rank != self.dst:
                 return None
             f = self.frames[slot]
-            f.view(3, self.world, self.ws, self.h).copy_(self.stage[slot].permute(1, 0, 2, 3))
-            return f
-        for q in work:
-            q.wait()
-        return self.frames[slot] if self.rank == self.dst else None
+            f.view(self.batch, 3, self.world, self.ws, self.h).copy_(self.stage[slot].permute(1, 2, 0, 3, 4))
+        else:
+            for q in work:
+                q.wait()
+            if self.rank != self.dst:
+                return None
+            f = self.frames[slot]
+        return f[0] if self.batch == 1 else f
 
 
 def gather_frame(slab, w, h, dist, dst=0):

@@ -124,3 +124,62 @@ def test_pipelined_gatherer_keeps_frames_apart(tmp_path, oracle):
         ref = oracle.render(128, 128, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
                             raygen=raygen_closed_form(128, 128, 45.0), want=("u8",))["u8"]
         assert np.array_equal(got[f"f{i}"], ref), f"frame {i}"
+
+
+def _batch_worker(rank, world, port, case, batch, nframes, out_path):
+    """FrameGatherer(batch=F): F frames per exchange, two exchanges in flight, last batch partly filled."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from python_ray_tracer_amd.distributed import slab_bounds, FrameGatherer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = load_frame(case)
+    w, h = int(g["w"]), int(g["h"])
+    x0, x1 = slab_bounds(w, world, rank)
+    gat = FrameGatherer(w, h, torch.uint8, torch.device("cpu"), dist, dst=0, slots=2, batch=batch)
+    slabs = [torch.zeros((batch, 3, x1 - x0, h), dtype=torch.uint8) for _ in range(2)]
+    first, got = [None, None], {}
+
+    def collect(b):
+        f = gat.finish(b)
+        if rank == 0:
+            f = f if batch > 1 else f.unsqueeze(0)
+            for j in range(batch):
+                if first[b] + j < nframes:
+                    got[first[b] + j] = f[j].numpy().copy()
+        first[b] = None
+    for i in range(nframes):
+        b, j = (i // batch) % 2, i % batch
+        if j == 0 and first[b] is not None:
+            collect(b)
+        r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
+                       raygen=raygen_closed_form(w, h, float(g["fov"])), x0=x0, x1=x1, want=("u8",), nthreads=2)
+        slabs[b][j].copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
+        if j == 0:
+            first[b] = i
+        if j == batch - 1 or i == nframes - 1:
+            gat.submit(slabs[b], b)
+    for b in ((nframes - 1) // batch % 2 + 1) % 2, (nframes - 1) // batch % 2:      # oldest first
+        if first[b] is not None:
+            collect(b)
+    if rank == 0:
+        np.savez(out_path, **{f"f{i}": v for i, v in got.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case,batch,nframes", [(2, "c1_128", 3, 8), (3, "odd_37x29", 2, 5)])
+def test_batched_gather(tmp_path, oracle, world, case, batch, nframes):
+    """Equal slabs (one gather per F frames) and ragged slabs (point-to-point), last batch partly filled."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frames.npz")
+    mp.spawn(_batch_worker, args=(world, _free_port(), case, batch, nframes, out), nprocs=world, join=True)
+    got = np.load(out)
+    g = load_frame(case)
+    w, h = int(g["w"]), int(g["h"])
+    for i in range(nframes):
+        ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
+                            raygen=raygen_closed_form(w, h, float(g["fov"])), want=("u8",))["u8"]
+        assert np.array_equal(got[f"f{i}"], ref), f"frame {i}"

@@ -66,3 +66,16 @@ def test_bench_runs_under_torchrun_world1():
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["frame_matches_reference_sha256"] is True and j["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("extra", [["--frames-per-gather", "4", "--steps", "22"], ["--frames-per-gather", "1", "--streams", "2", "--steps", "9"]])
+def test_bench_exchange_structure_on_one_gpu(extra):
+    """The N > 1 choreography of bench.py (frames round-robin on render streams, slabs of F frames per RCCL gather
+    on a separate stream, two exchanges in flight, last batch partly filled) on a world-size-1 RCCL group."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--force-gather", "--warmup", "5", "--no-cpu-baseline"] + extra,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29546"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["frame_matches_reference_sha256"] is True and "gather" in j["config"]["parallelism"]
