@@ -106,8 +106,8 @@ __device__ __forceinline__ V3 normalize3_generic(const V3 &v)
 // both correctly rounded.  For operands well inside the exponent range the scaling steps are identities, so
 // the sequences below return bit-identical results while the reciprocal refinement (5 of a division's 11
 // instructions) is shared by x/n, y/n, z/n and the sqrt skips its range handling: 29 instructions instead
-// of 55.  Guard (wave-uniform): |v|² in [2^-400, 2^400] and every component nonzero with magnitude
-// >= 2^-500 (so no intermediate leaves the normal range and no signed-zero case arises); otherwise the
+// of 55.  Guard (wave-uniform): every component's magnitude >= 2^-200 (hence nonzero, and |v|² >= 2^-400) and
+// |v|² <= 2^400, so no intermediate leaves the normal range and no signed-zero case arises; otherwise the
 // generic path.  tests/test_algorithms.py replays this on the CPU against sqrt()/division on 10^8 vectors
 // with seeds 16x less accurate than v_rsq_f64 / v_rcp_f64.
 __device__ __forceinline__ V3 normalize3(const V3 &v)
@@ -116,11 +116,8 @@ __device__ __forceinline__ V3 normalize3(const V3 &v)
     return normalize3_generic(v);
 #else
     const double nn = v.x * v.x + v.y * v.y + v.z * v.z;
-    const unsigned ex = (unsigned)__double2hiint(v.x) & 0x7fffffffu, ey = (unsigned)__double2hiint(v.y) & 0x7fffffffu,
-                   ez = (unsigned)__double2hiint(v.z) & 0x7fffffffu;
-    const unsigned emin = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
-    const bool ok = (emin >= ((1023u - 500u) << 20)) &&
-                    ((unsigned)__double2hiint(nn) - ((1023u - 400u) << 20) < (800u << 20));
+    const double cmin = __builtin_fmin(__builtin_fmin(__builtin_fabs(v.x), __builtin_fabs(v.y)), __builtin_fabs(v.z));
+    const bool ok = (cmin >= 0x1p-200) && (nn <= 0x1p400);                  // NaNs fail both
     if (__ballot(!ok) != 0ull) return normalize3_generic(v);
     const double y = __builtin_amdgcn_rsq(nn);
     double g = nn * y, h = 0.5 * y;
@@ -142,31 +139,33 @@ __device__ __forceinline__ V3 normalize3(const V3 &v)
 // normalize() of a vector that is ALREADY unit length (every direction a scene query receives is
 // the output of a normalize) — bit-identical to normalize3(), without the generic sqrt and divides.
 //
-//   nn = fl(x²+y²+z²) lies within a few ulp of 1.  With eps = 2^-52:
-//     nn = 1 + k·eps   (k >= 0):  sqrt = 1 + (k/2)eps - (k²/8)eps² ..  ->  RN = 1 + floor(k/2)·eps
-//     nn = 1 - j·eps/2 (j >= 1):  sqrt = 1 - (j/4)eps - ..             ->  RN = 1 - ceil(j/2)·eps/2
-//   (the second-order term only decides which side of a midpoint the value falls on), and both k and
-//   j are differences of the IEEE bit patterns from that of 1.0, so nrm = RN(sqrt(nn)) is integer work.
-//   y = RN(1/nrm) follows the same way:  nrm = 1 + m·eps -> y = 1 - m·eps (= 1 - 2m·eps/2);
-//   nrm = 1 - i·eps/2 -> y = 1 + ceil(i/2)·eps.
-//   Each quotient x/nrm is then  q1 = fma(-x, nrm-1, x)  (faithful: off by |x|·(nrm-1)² at most),
+//   nn = fl(x²+y²+z²) lies within a few ulp of 1; e = nn - 1 is exact.  With eps = 2^-52:
+//     e = k·eps    (k >= 0):  sqrt = 1 + e/2 - e²/8 ..  ->  RN = 1 + floor(k/2)·eps
+//     e = -j·eps/2 (j >= 1):  sqrt = 1 + e/2 - e²/8 ..  ->  RN = 1 - ceil(j/2)·eps/2
+//   i.e. RN(sqrt(nn)) is 1 + e/2 rounded to nearest with every tie (odd k, odd j) resolved downward, because
+//   the second-order term is negative.  One fma rounds exactly once, so nudging e toward -inf by a relative
+//   2^-30 first (e2 = e - |e|·2^-30, far below half a grid step, far above e²/8) makes
+//   nrm = fma(e2, 1/2, 1) that value: the nudge decides the ties and moves nothing else.
+//   y = RN(1/nrm) likewise: with dl = nrm - 1 (exact), 1/nrm = 1 - dl + dl² .., ties (dl = -i·eps/2, i odd)
+//   resolved upward: y = fma(-dl, 1 + 2^-30, 1).
+//   Each quotient x/nrm is then  q1 = fma(-x, dl, x)  (faithful: off by |x|·dl² at most),
 //   r = fma(-q1, nrm, x) (the exact remainder),  q = fma(r, y, q1)  — Markstein's final correction,
 //   which returns the correctly rounded quotient RN(x/nrm) given y = RN(1/nrm) and a faithful q1.
-// Falls back to the generic path (wave-uniformly) if any live lane's nn is not within 2^-32 of 1.
-// tests/test_algorithms.py replays this routine on the CPU against sqrt-and-divide on 10^7 vectors.
+// Falls back to the generic path (wave-uniformly) if any live lane's nn is not within 2^-33 of 1.
+// tests/test_algorithms.py replays this routine on the CPU: nrm and y against sqrt and division for EVERY double
+// within 2^-33 of 1 (1.57 million), the whole routine against sqrt-and-divide on 10^7 vectors.
+// (The same values used to be derived from the IEEE bit pattern with 64-bit integer arithmetic: ~25 more
+// instructions per call, 13 calls per tile — one in seven of all the kernel's VALU instructions.)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ V3 renormalize_unit(const V3 &d)
 {
     const double nn = d.x * d.x + d.y * d.y + d.z * d.z;
-    constexpr long long ONE = 0x3FF0000000000000ll;
-    const long long k = __double_as_longlong(nn) - ONE;
-    const bool near1 = (k > -(1ll << 20)) && (k < (1ll << 20));
-    if (__ballot(!near1) != 0ull) return normalize3_generic(d);
-    long long nb, yb;
-    if (k >= 0) { const long long m = k >> 1; nb = ONE + m; yb = ONE - 2 * m; }
-    else        { const long long i = (1 - k) >> 1; nb = ONE - i; yb = ONE + ((i + 1) >> 1); }
-    const double nrm = __longlong_as_double(nb), y = __longlong_as_double(yb);
+    const double e = nn - 1.0;                                     // exact
+    if (__ballot(!(__builtin_fabs(e) < 0x1p-33)) != 0ull) return normalize3_generic(d);
+    const double e2 = __builtin_fma(-__builtin_fabs(e), 0x1p-30, e);
+    const double nrm = __builtin_fma(e2, 0.5, 1.0);                // RN(sqrt(nn))
     const double dl = nrm - 1.0;                                   // exact
+    const double y = __builtin_fma(-dl, 1.0 + 0x1p-30, 1.0);       // RN(1/nrm)
     V3 q{__builtin_fma(-d.x, dl, d.x), __builtin_fma(-d.y, dl, d.y), __builtin_fma(-d.z, dl, d.z)};
     const V3 r{__builtin_fma(-q.x, nrm, d.x), __builtin_fma(-q.y, nrm, d.y), __builtin_fma(-q.z, nrm, d.z)};
     q = V3{__builtin_fma(r.x, y, q.x), __builtin_fma(r.y, y, q.y), __builtin_fma(r.z, y, q.z)};
@@ -415,6 +414,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
       {   // the float32 ray is rebuilt per chunk (10 ops) so that it is not live during the float64 phase
           const RayF qf = make_rayf(o, R, p.extent2);
           mask = cull_mask(lds, S, canchor, k0, n, qf, -1, false);
+          mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);   // padding slots certify themselves, except to a NaN ray
       }
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
@@ -479,6 +479,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
           const RayF qf = make_rayf(o, R, p.extent2);
           const bool self_culled = (canchor >= 0 && self >= k0 && self < k0 + n) ? cull_origin(lds.sph32 + 4 * self, qf) : false;
           mask = cull_mask(lds, S, canchor, k0, n, qf, self, self_culled);
+          mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);
       }
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);

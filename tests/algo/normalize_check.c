@@ -1,8 +1,9 @@
 /* CPU replay of rt_device.h's normalize3() fast path: sqrt by one rsq seed + Goldschmidt/Newton steps (the
  * sequence the AMDGPU backend emits for f64 sqrt, without its range scaling), one refined reciprocal shared by
  * the three quotients, one fma correction per quotient (the backend's f64 division without div_scale/div_fixup).
- * Seeds are float32-accurate here (2^-24), i.e. WORSE than v_rsq_f64 / v_rcp_f64, so agreement with
- * sqrt()/division on every sample is a conservative check.  Built and run by tests/test_algorithms.py. */
+ * Seeds carry a relative error of up to 2^-24 here, i.e. WORSE than v_rsq_f64 / v_rcp_f64, so agreement with
+ * sqrt()/division on every sample is a conservative check.  One sample in four sits at the edges of the guard
+ * (components down to 2^-200, |v|^2 up to 2^400).  Built and run by tests/test_algorithms.py. */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,14 +23,14 @@ static void normalize_ref(const double v[3], double out[3])
 static void normalize_fast(const double v[3], double out[3], double *norm)
 {
     const double nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    double y = (double)(1.0f / sqrtf((float)nn));          /* stand-in for v_rsq_f64 */
+    double y = (1.0 / sqrt(nn)) * (1.0 + (urand() * 2 - 1) * 0x1p-24);   /* stand-in for v_rsq_f64 */
     double g = nn * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     double d = fma(-g, g, nn); g = fma(d, h, g);
     d = fma(-g, g, nn); g = fma(d, h, g);
     *norm = g;
-    double r0 = (double)(1.0f / (float)g);                  /* stand-in for v_rcp_f64 */
+    double r0 = (1.0 / g) * (1.0 + (urand() * 2 - 1) * 0x1p-24);         /* stand-in for v_rcp_f64 */
     double e = fma(-g, r0, 1.0); r0 = fma(r0, e, r0);
     e = fma(-g, r0, 1.0); r0 = fma(r0, e, r0);
     for (int c = 0; c < 3; ++c) {
@@ -44,10 +45,17 @@ int main(int argc, char **argv)
     long n = argc > 1 ? atol(argv[1]) : 10000000, bad = 0, badsqrt = 0;
     for (long it = 0; it < n; ++it) {
         double v[3], a[3], b[3], nr;
-        int mode = it & 3;
+        int mode = it & 7;
         double sc = mode == 0 ? 1.0 : exp((urand() - 0.5) * (mode == 1 ? 8 : 60));   /* magnitudes 1e-13 .. 1e13 */
+        if (mode == 4) sc = ldexp(1.0, 190 + (int)(rnd() % 9));                      /* |v|^2 just below 2^400 */
+        if (mode == 5) sc = ldexp(1.0, -(185 + (int)(rnd() % 14)));                  /* components around 2^-200 */
         for (int c = 0; c < 3; ++c) v[c] = (urand() * 2 - 1) * sc;
         if (mode == 3) v[(int)(rnd() % 3)] *= exp(-urand() * 60);                    /* one component much smaller */
+        if (mode == 6) v[(int)(rnd() % 3)] = ldexp(0.5 + urand() * 0.5, -199);        /* one component at the guard, others O(1) */
+        {   /* the guard of rt_device.h: outside it the kernel takes the generic path */
+            const double cmin = fmin(fmin(fabs(v[0]), fabs(v[1])), fabs(v[2]));
+            if (!(cmin >= 0x1p-200 && v[0] * v[0] + v[1] * v[1] + v[2] * v[2] <= 0x1p400)) continue;
+        }
         normalize_ref(v, a);
         normalize_fast(v, b, &nr);
         if (nr != sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])) badsqrt++;

@@ -1,4 +1,4 @@
-/* CPU replay of rt_device.h's renormalize_unit(): the integer-sqrt + Markstein-quotient shortcut must equal
+/* CPU replay of rt_device.h's renormalize_unit(): the two-fma sqrt/reciprocal + Markstein-quotient shortcut must equal
  * sqrt-and-divide normalisation bit for bit on unit-length inputs.  Built and run by tests/test_algorithms.py. */
 #include <math.h>
 #include <stdint.h>
@@ -15,25 +15,52 @@ static void normalize_ref(const double v[3], double out[3])
     out[0] = v[0] / n; out[1] = v[1] / n; out[2] = v[2] / n;
 }
 
+/* sqrt and reciprocal of a value within 2^-33 of 1, as rt_device.h evaluates them: no integer work, no select.
+ * Returns 0 if nn is outside the accepted range. */
+static int unit_sqrt_rcp(double nn, double *nrm_out, double *y_out)
+{
+    const double e = nn - 1.0;                               /* exact */
+    if (!(fabs(e) < 0x1p-33)) return 0;
+    const double e2 = fma(-fabs(e), 0x1p-30, e);             /* nudged toward -inf: decides the ties of 1 + e/2 */
+    const double nrm = fma(e2, 0.5, 1.0);
+    const double dl = nrm - 1.0;                             /* exact */
+    const double y = fma(-dl, 1.0 + 0x1p-30, 1.0);
+    *nrm_out = nrm; *y_out = y;
+    return 1;
+}
+
 /* returns 0 if the fast path does not apply */
 static int renormalize_unit(const double d[3], double out[3])
 {
     const double nn = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    const int64_t ONE = 0x3FF0000000000000ll;
-    const int64_t k = bits(nn) - ONE;
-    if (!(k > -(1ll << 20) && k < (1ll << 20))) return 0;
-    int64_t nb, yb;
-    if (k >= 0) { int64_t m = k >> 1; nb = ONE + m; yb = ONE - 2 * m; }
-    else        { int64_t i = (1 - k) >> 1; nb = ONE - i; yb = ONE + ((i + 1) >> 1); }
-    const double nrm = from_bits(nb), y = from_bits(yb), dl = nrm - 1.0;
+    double nrm, y;
+    if (!unit_sqrt_rcp(nn, &nrm, &y)) return 0;
+    const double dl = nrm - 1.0;
     for (int c = 0; c < 3; ++c) {
         double q = fma(-d[c], dl, d[c]);
         double r = fma(-q, nrm, d[c]);
         out[c] = fma(r, y, q);
     }
-    /* also check the integer sqrt / reciprocal themselves */
     if (nrm != sqrt(nn) || y != 1.0 / nrm) return -1;
     return 1;
+}
+
+/* every double within 2^-33 of 1: RN(sqrt) and RN(1/RN(sqrt)) against libm / IEEE division */
+static long sweep(void)
+{
+    const int64_t ONE = 0x3FF0000000000000ll;
+    long bad = 0, n = 0;
+    for (int64_t k = -(1ll << 21); k <= (1ll << 20); ++k) {
+        const double nn = from_bits(ONE + k);
+        double nrm, y;
+        if (!unit_sqrt_rcp(nn, &nrm, &y)) continue;
+        ++n;
+        if (nrm != sqrt(nn) || y != 1.0 / nrm) {
+            if (bad++ < 5) fprintf(stderr, "SWEEP MISMATCH k=%lld nrm=%a sqrt=%a y=%a rcp=%a\n", (long long)k, nrm, sqrt(nn), y, 1.0 / nrm);
+        }
+    }
+    printf("sweep=%ld sweep_mismatches=%ld\n", n, bad);
+    return bad;
 }
 
 static uint64_t s[2] = {0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull};
@@ -42,7 +69,7 @@ static inline double urand(void) { return (double)(rnd() >> 11) * (1.0 / 9007199
 
 int main(int argc, char **argv)
 {
-    long n = argc > 1 ? atol(argv[1]) : 10000000, bad = 0, fast = 0, wide = 0;
+    long n = argc > 1 ? atol(argv[1]) : 10000000, bad = sweep(), fast = 0, wide = 0;
     for (long it = 0; it < n; ++it) {
         double v[3], d[3], a[3], b[3];
         int mode = it & 7;
