@@ -104,9 +104,11 @@ __device__ __forceinline__ V3 normalize3_generic(const V3 &v)
 //   a / b:    r = rcp(b); twice { e = fma(-b,r,1); r = fma(r,e,r); }  q = a*r; res = fma(fma(-b,q,a), r, q)
 //                                                                             (+ div_scale / div_fixup)
 // both correctly rounded.  For operands well inside the exponent range the scaling steps are identities, so
-// the sequences below return bit-identical results while the reciprocal refinement (5 of a division's 11
-// instructions) is shared by x/n, y/n, z/n and the sqrt skips its range handling: 29 instructions instead
-// of 55.  Guard (wave-uniform): every component's magnitude >= 2^-200 (hence nonzero, and |v|² >= 2^-400) and
+// the sequences below return bit-identical results while the reciprocal (5 of a division's 11 instructions) is
+// shared by x/n, y/n, z/n and the sqrt skips its range handling.  The reciprocal itself needs no v_rcp_f64
+// (a quarter-rate instruction): the sqrt iteration's h already approximates 1/(2g) to ~2^-50, so one Newton
+// step from 2h lands where the backend's two steps from the rcp seed land — within half an ulp (+2^-47) of
+// 1/g, which is what the final fma correction of each quotient requires.  26 instructions instead of 55.  Guard (wave-uniform): every component's magnitude >= 2^-200 (hence nonzero, and |v|² >= 2^-400) and
 // |v|² <= 2^400, so no intermediate leaves the normal range and no signed-zero case arises; otherwise the
 // generic path.  tests/test_algorithms.py replays this on the CPU against sqrt()/division on 10^8 vectors
 // with seeds 16x less accurate than v_rsq_f64 / v_rcp_f64.
@@ -125,9 +127,8 @@ __device__ __forceinline__ V3 normalize3(const V3 &v)
     g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
     double d = __builtin_fma(-g, g, nn); g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, nn); g = __builtin_fma(d, h, g);               // g = RN(sqrt(nn))
-    double rc = __builtin_amdgcn_rcp(g);
-    double e = __builtin_fma(-g, rc, 1.0); rc = __builtin_fma(rc, e, rc);
-    e = __builtin_fma(-g, rc, 1.0); rc = __builtin_fma(rc, e, rc);
+    double rc = 2.0 * h;                                                    // h ~ 1/(2g), relative error ~2^-50
+    const double e = __builtin_fma(-g, rc, 1.0); rc = __builtin_fma(rc, e, rc);   // within 1/2 ulp(1 + 2^-47) of 1/g
     const double qx = v.x * rc, qy = v.y * rc, qz = v.z * rc;
     return V3{__builtin_fma(__builtin_fma(-g, qx, v.x), rc, qx),
               __builtin_fma(__builtin_fma(-g, qy, v.y), rc, qy),

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--aa", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help=">1: frames round-robin on that many streams, wall-clock per frame")
     a = ap.parse_args()
     import numpy as np
     import python_ray_tracer_amd as pkg
@@ -35,16 +36,31 @@ def main():
         r = pkg.Renderer(0, lib=_lib.bind(os.path.abspath(so)))
         r.set_scene(wl["spheres"], wl["lights"], wl["planes"]); r.set_camera(cam.position, cam.rotation); r.set_raygen(w, h, *cam.raygen())
         d8, d32 = r.malloc(3 * w * h), r.malloc(12 * w * h)
+        if a.streams > 1:
+            r._ab_streams = [r.stream_create() for _ in range(a.streams)]
+            r._ab_bufs = [(d8, d32)] + [(r.malloc(3 * w * h), r.malloc(12 * w * h)) for _ in range(a.streams - 1)]
         rs.append((path, r, d8, d32))
     ps = {path: pkg.Renderer.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 1 if a.aa else wl["aa"], flags=flags[path],
                                     spp=wl["spp"], seed=wl["seed"]) for path in a.libs}
     times = {path: [] for path, *_ in rs}
     for rnd in range(a.rounds + 2):
         for path, r, d8, d32 in rs:
-            r.timer_begin()
-            for _ in range(a.launches):
-                r.render_device(ps[path], 0, w, d8, d32, w * h)
-            ms = r.timer_end() / a.launches
+            if a.streams > 1:
+                import time
+                for s_ in r._ab_streams:
+                    r.sync(s_)
+                t0 = time.perf_counter()
+                for i in range(a.launches):
+                    b8, b32 = r._ab_bufs[i % a.streams]
+                    r.render_device(ps[path], 0, w, b8, b32, w * h, stream=r._ab_streams[i % a.streams])
+                for s_ in r._ab_streams:
+                    r.sync(s_)
+                ms = (time.perf_counter() - t0) * 1e3 / a.launches
+            else:
+                r.timer_begin()
+                for _ in range(a.launches):
+                    r.render_device(ps[path], 0, w, d8, d32, w * h)
+                ms = r.timer_end() / a.launches
             if rnd >= 2:
                 times[path].append(ms)
     out = {}
