@@ -136,6 +136,10 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.anchors = (table <= (size_t)rt::MAX_CULL_TABLE_BYTES) ? ctx->L + 1 : 0;
     const double cam2 = ctx->cam_o[0] * ctx->cam_o[0] + ctx->cam_o[1] * ctx->cam_o[1] + ctx->cam_o[2] * ctx->cam_o[2];
     k.extent2 = (float)(1.0001 * (cam2 > ctx->scene_extent2 ? cam2 : ctx->scene_extent2));
+    {   // every ray origin of the launch lies within |cam| + 999 (depth + 1) of the world origin
+        const double reach = std::sqrt(cam2) + 999.0 * (p->depth + 1) + std::sqrt(ctx->scene_extent2);
+        k.floor_anch = (float)(0x1p-39 * reach * reach);
+    }
     // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 6 workgroups per CU still
     // fit their LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
     const bool aa = k.aa != 0;

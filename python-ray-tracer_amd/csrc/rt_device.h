@@ -78,7 +78,8 @@ struct KParams {
     int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
     unsigned seed;             // jitter hash seed (stochastic AA)
     int u8_hwc;                // uint8 frame interleaved as [y][x][3] (an image), row pitch = plane_stride pixels
-    float extent2, pad1;       // max squared distance of camera / lights / sphere surfaces from the world origin
+    float extent2, floor_anch; // max squared distance of camera / lights / sphere surfaces from the world origin;
+                               // launch-constant floor of the anchored cull (host: 2^-39 (|cam| + 999(depth+1) + extent)²)
     double px, y0, dy, z0, dz;
     double cam_o[3];
     double cam_R[9];
@@ -207,7 +208,8 @@ template <bool PARK> struct Park3 {
 //  * anchored form — every primary ray passes through the camera and every shadow ray through its
 //    light, so with A = camera/light the vector A-c, w = r2-|A-c|² and the error margin are
 //    constants per (anchor, sphere): a table built once per workgroup in LDS (from float64), and
-//    the per-ray work is s' = (A-c)·R32 (3 ops), D' = fma(s',s',w), one compare;
+//    the per-ray work is s' = (A-c)·R32 (3 ops) and ONE compare, |s'| < tau, with
+//    tau = sqrt(|A-c|² - r2 - margin - floor) rounded down (D' = s'² + r2 - |A-c|² < -margin - floor);
 //  * origin form — for reflection rays, and for the sphere a shadow ray starts on, L = o32 - c is
 //    formed per lane; it also certifies "behind" (s > e_s and |L|²-r2 > e_c).
 //
@@ -218,7 +220,10 @@ template <bool PARK> struct Park3 {
 //               |s' - s| <= u(|o| + 5Λ)                  margin used:  8u(1 + Λ² + |o|²)
 //               |c' - c| <= u(7Λ² + |o|² + r2)           margin used: 64u(Λ² + |o|² + r2)
 // plus, in all of them, floor = 2^-40(|o|² + extent²) >= the float64 rounding of the reference's own
-// D (<= 2^-50 of its operands) and the distance by which a float64 direction misses its anchor.
+// D (<= 2^-50 of its operands) and the distance by which a float64 direction misses its anchor.  The anchored
+// form uses a launch constant for it: every ray origin lies within |cam| + 999(depth+1) of the world origin
+// (each segment of a path is shorter than the far limit), so floor_anch = 2^-39(|cam| + 999(depth+1) + extent)²
+// bounds it for every query of the launch.
 // A sphere is skipped only if EVERY live lane holds a certificate; NaNs certify nothing.
 // ---------------------------------------------------------------------------------------------
 constexpr float CULL_K_ANCHOR = 0x1p-19f * 1.0001f;
@@ -244,30 +249,44 @@ struct RayF {              // float32 shadow of a query, for the cull only
     float oo, floorq;
 };
 
-__device__ __forceinline__ RayF make_rayf(const V3 &o, const V3 &R, float extent2)
+// The anchored form needs the direction only; the origin terms are added where the origin form is used.
+__device__ __forceinline__ RayF make_rayf_dir(const V3 &R)
 {
     RayF q;
-    q.o = F3{(float)o.x, (float)o.y, (float)o.z};
+    q.o = F3{0.0f, 0.0f, 0.0f};
     q.R = F3{(float)R.x, (float)R.y, (float)R.z};
+    q.oo = 0.0f; q.floorq = 0.0f;
+    return q;
+}
+__device__ __forceinline__ void add_origin(RayF &q, const V3 &o, float extent2)
+{
+    q.o = F3{(float)o.x, (float)o.y, (float)o.z};
     q.oo = __builtin_fmaf(q.o.z, q.o.z, __builtin_fmaf(q.o.y, q.o.y, q.o.x * q.o.x));
     q.floorq = CULL_K_FLOOR * (q.oo + extent2);
-    return q;
+}
+
+// tau of one (anchor, sphere) pair: the line through the anchor with unit direction R misses the sphere by more
+// than every error the budget above allows when |(A-c).R32| < tau.  ll = |A-c|² (float64).
+__device__ __forceinline__ float anchored_tau(double ll, double r2, float floor_anch)
+{
+    const double W = ((ll - r2) - (ll + r2) * (double)CULL_K_ANCHOR) - (double)floor_anch;
+    if (!(W > 0.0)) return 0.0f;                              // anchor inside or too close (or NaN): never certified
+    return (float)(__builtin_sqrt(W) * (1.0 - 0x1p-20));      // rounded down: the float32 rounding is within 2^-24
 }
 
 // true = this lane holds a certificate that sphere k reports a miss for this ray (anchored form)
 __device__ __forceinline__ bool cull_anchored(const float *__restrict__ e, const RayF &q)
 {
     const float s = __builtin_fmaf(e[2], q.R.z, __builtin_fmaf(e[1], q.R.y, e[0] * q.R.x));
-    const float D = __builtin_fmaf(s, s, e[3]);               // e[3] = r2 - |A-c|² + margin
-    return D < -q.floorq;
+    return __builtin_fabsf(s) < e[3];                         // e[3] = tau (0: never, +inf: padding, always)
 }
 
 // Phase 1 of a scene query: one bit per sphere of the chunk [k0, k0+n), set when SOME live lane holds
 // no certificate.  Straight-line float32 work with no dependence between spheres; the mask is
 // wave-uniform (it is built from ballots), so phase 2 — the float64 test — runs only for set bits.
-// self / self_culled: the sphere a shadow ray starts on and its origin-form certificate.
+// self: the sphere a shadow ray starts on (-1: none), certified by the origin form's "behind" test.
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const RayF &q, int self, bool self_culled);
+                                                        const V3 &o, const V3 &R, float extent2, int self);
 
 // origin form: line-miss or behind certificate
 __device__ __forceinline__ bool cull_origin(const float *__restrict__ c, const RayF &q)
@@ -353,12 +372,21 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
 }
 
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const RayF &q, int self, bool self_culled)
+                                                        const V3 &o, const V3 &R, float extent2, int self)
 {
-    const int selfj = self_culled ? self - k0 : -1;                           // per lane
-    if (__ballot(self_culled) != 0ull)                                        // only shadow rays leaving a sphere
-        return (anchor >= 0) ? cull_mask_t<true, true>(lds, S, anchor, k0, n, q, selfj) : cull_mask_t<false, true>(lds, S, anchor, k0, n, q, selfj);
-    return (anchor >= 0) ? cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1) : cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1);
+    RayF q = make_rayf_dir(R);
+    if (anchor >= 0) {
+        const bool cand = self >= k0 && self < k0 + n;                        // per lane
+        if (__ballot(cand) != 0ull) {                                         // only shadow rays leaving a sphere
+            add_origin(q, o, extent2);
+            const bool self_culled = cand ? cull_origin(lds.sph32 + 4 * self, q) : false;
+            if (__ballot(self_culled) != 0ull)
+                return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1);
+        }
+        return cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1);
+    }
+    add_origin(q, o, extent2);
+    return cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -412,11 +440,9 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
-      {   // the float32 ray is rebuilt per chunk (10 ops) so that it is not live during the float64 phase
-          const RayF qf = make_rayf(o, R, p.extent2);
-          mask = cull_mask(lds, S, canchor, k0, n, qf, -1, false);
-          mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);   // padding slots certify themselves, except to a NaN ray
-      }
+      // the float32 ray is rebuilt per chunk so that it is not live during the float64 phase
+      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, -1);
+      mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);       // padding slots certify themselves, except to a NaN ray
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
@@ -476,12 +502,8 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
-      {
-          const RayF qf = make_rayf(o, R, p.extent2);
-          const bool self_culled = (canchor >= 0 && self >= k0 && self < k0 + n) ? cull_origin(lds.sph32 + 4 * self, qf) : false;
-          mask = cull_mask(lds, S, canchor, k0, n, qf, self, self_culled);
-          mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-      }
+      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, self);
+      mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
         for (int e = threadIdx.x; e < p.anchors * Sp; e += WG_THREADS) {
             const int a = e / Sp, k = e - a * Sp;
             float *t = tab + (size_t)e * CULL_STRIDE;
-            if (k >= p.S) { t[0] = t[1] = t[2] = 0.0f; t[3] = NINF; continue; }   // padding: always culled
+            if (k >= p.S) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }   // padding: always culled
             const double *g = lds_raw + k * SPH_STRIDE;
             const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
             const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
@@ -711,7 +733,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
             const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
             const double ll = lx * lx + ly * ly + lz * lz;
             t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
-            t[3] = (float)((g[3] - ll) + (ll + g[3]) * (double)CULL_K_ANCHOR);     // w + margin
+            t[3] = anchored_tau(ll, g[3], p.floor_anch);
         }
         // the same two tables for the cluster bounding spheres (float64 records in global memory, after the
         // lights; rounding the centre to float32 is covered by rounding R2 up)
@@ -726,7 +748,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
         for (int e = threadIdx.x; e < p.anchors * NCp; e += WG_THREADS) {
             const int a = e / NCp, c = e - a * NCp;
             float *t = ctab + (size_t)e * CULL_STRIDE;
-            if (c >= p.NC) { t[0] = t[1] = t[2] = 0.0f; t[3] = NINF; continue; }
+            if (c >= p.NC) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }
             const double *g = cl + c * CL_STRIDE;
             const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
             const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
@@ -734,7 +756,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
             const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
             const double ll = lx * lx + ly * ly + lz * lz;
             t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
-            t[3] = (float)((g[3] - ll) + (ll + g[3]) * (double)CULL_K_ANCHOR);
+            t[3] = anchored_tau(ll, g[3], p.floor_anch);
         }
     }
     __syncthreads();
