@@ -274,8 +274,21 @@ __device__ __forceinline__ float anchored_tau(double ll, double r2, float floor_
     return (float)(__builtin_sqrt(W) * (1.0 - 0x1p-20));      // rounded down: the float32 rounding is within 2^-24
 }
 
+// Table entries are read through a 32-bit LDS address that is pinned in a VGPR (the empty asm): the index is
+// wave-uniform, and left to itself the compiler forms every entry's address on the scalar unit and moves it
+// into a VGPR for its ds_read — one extra VALU instruction per sphere.  With the base in a VGPR the entries of
+// a group are immediate offsets of one 16-byte ds_read_b128 each.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f4 lds_cf4;
+__device__ __forceinline__ lds_cf4 *pin_lds(const float *generic)
+{
+    unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)generic;
+    asm volatile("" : "+v"(a));
+    return (lds_cf4 *)(size_t)a;
+}
+
 // true = this lane holds a certificate that sphere k reports a miss for this ray (anchored form)
-__device__ __forceinline__ bool cull_anchored(const float *__restrict__ e, const RayF &q)
+__device__ __forceinline__ bool cull_anchored(const f4 e, const RayF &q)
 {
     const float s = __builtin_fmaf(e[2], q.R.z, __builtin_fmaf(e[1], q.R.y, e[0] * q.R.x));
     return __builtin_fabsf(s) < e[3];                         // e[3] = tau (0: never, +inf: padding, always)
@@ -289,7 +302,7 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
                                                         const V3 &o, const V3 &R, float extent2, int self);
 
 // origin form: line-miss or behind certificate
-__device__ __forceinline__ bool cull_origin(const float *__restrict__ c, const RayF &q)
+__device__ __forceinline__ bool cull_origin(const f4 c, const RayF &q)
 {
     const float lx = q.o.x - c[0], ly = q.o.y - c[1], lz = q.o.z - c[2];
     const float s = __builtin_fmaf(lz, q.R.z, __builtin_fmaf(ly, q.R.y, lx * q.R.x));
@@ -327,13 +340,16 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // handling and use immediate LDS offsets (the compiler packs the four independent chains into
 // v_pk_mul/fma_f32, two spheres per instruction).
 template <bool ANCH, bool SELF>
-__device__ __forceinline__ unsigned cull4(const float *__restrict__ base, const RayF &q, int jsel)
+__device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel)
 {
+    static_assert(CULL_STRIDE == 4, "one 16-byte entry per (anchor, sphere)");
     unsigned bits = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+        asm volatile("" ::: "memory");                        // one entry in flight (registers decide occupancy)
+        const f4 e = base[u];
         bool culled;
-        if constexpr (ANCH) culled = cull_anchored(base + u * CULL_STRIDE, q); else culled = cull_origin(base + 4 * u, q);
+        if constexpr (ANCH) culled = cull_anchored(e, q); else culled = cull_origin(e, q);
         if constexpr (SELF) culled = culled || (u == jsel);   // the sphere this lane's shadow ray starts on
         bits |= (unsigned)any_lane(!culled) << u;
     }
@@ -350,23 +366,23 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
 {
     unsigned long long mask = 0ull;
     const int Sp = padS(S, lds.NC);
-    const float *sbase = ANCH ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0;
+    lds_cf4 *sbase = pin_lds(ANCH ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0);
     if (lds.NC > 0) {
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
-        const float *cbase = ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0;
+        lds_cf4 *cbase = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0);
         unsigned cm = 0;
-        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j * 4, q, -1) << j;
+        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
             cm &= cm - 1u;
             const int jb = c * CLUSTER;
-            const unsigned lo = cull4<ANCH, SELF>(sbase + jb * 4, q, selfj - jb);
-            const unsigned hi = cull4<ANCH, SELF>(sbase + (jb + 4) * 4, q, selfj - jb - 4);
+            const unsigned lo = cull4<ANCH, SELF>(sbase + jb, q, selfj - jb);
+            const unsigned hi = cull4<ANCH, SELF>(sbase + jb + 4, q, selfj - jb - 4);
             mask |= (unsigned long long)(lo | (hi << 4)) << jb;
         }
     } else {
         const int npad = pad4(n);
-        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j * 4, q, selfj - j) << j;
+        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j) << j;
     }
     return mask;
 }
@@ -379,7 +395,8 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
         const bool cand = self >= k0 && self < k0 + n;                        // per lane
         if (__ballot(cand) != 0ull) {                                         // only shadow rays leaving a sphere
             add_origin(q, o, extent2);
-            const bool self_culled = cand ? cull_origin(lds.sph32 + 4 * self, q) : false;
+            const float *cs = lds.sph32 + 4 * self;
+            const bool self_culled = cand ? cull_origin(f4{cs[0], cs[1], cs[2], cs[3]}, q) : false;
             if (__ballot(self_culled) != 0ull)
                 return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1);
         }
