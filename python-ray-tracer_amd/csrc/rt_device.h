@@ -121,7 +121,7 @@ __device__ __forceinline__ V3 normalize3(const V3 &v)
     const double nn = v.x * v.x + v.y * v.y + v.z * v.z;
     const double cmin = __builtin_fmin(__builtin_fmin(__builtin_fabs(v.x), __builtin_fabs(v.y)), __builtin_fabs(v.z));
     const bool ok = (cmin >= 0x1p-200) && (nn <= 0x1p400);                  // NaNs fail both
-    if (__ballot(!ok) != 0ull) return normalize3_generic(v);
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return normalize3_generic(v);
     const double y = __builtin_amdgcn_rsq(nn);
     double g = nn * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
@@ -163,7 +163,7 @@ __device__ __forceinline__ V3 renormalize_unit(const V3 &d)
 {
     const double nn = d.x * d.x + d.y * d.y + d.z * d.z;
     const double e = nn - 1.0;                                     // exact
-    if (__ballot(!(__builtin_fabs(e) < 0x1p-33)) != 0ull) return normalize3_generic(d);
+    if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(e) < 0x1p-33)) != 0ull) return normalize3_generic(d);
     const double e2 = __builtin_fma(-__builtin_fabs(e), 0x1p-30, e);
     const double nrm = __builtin_fma(e2, 0.5, 1.0);                // RN(sqrt(nn))
     const double dl = nrm - 1.0;                                   // exact
@@ -314,14 +314,15 @@ __device__ __forceinline__ bool cull_origin(const f4 c, const RayF &q)
     return (D < -mg) || (s > es && cc > mg);
 }
 
-// 1 if some live lane's predicate holds — decided and kept on the scalar unit (a C expression on the ballot
-// word is lowered through v_cndmask + v_readfirstlane)
-__device__ __forceinline__ unsigned long long any_lane(bool pred)
+// acc = 2 acc + (some live lane's predicate holds) — decided and kept on the scalar unit in two instructions (a C
+// expression on the ballot word is lowered through v_cndmask + v_readfirstlane; compare + select + shift + or is
+// four).  Each CU has ONE scalar ALU for its four SIMDs and this kernel keeps it ~70 % busy, so scalar
+// instructions are not free here: the cull's mask building is its largest share.
+__device__ __forceinline__ unsigned push_any_lane(unsigned acc, bool pred)
 {
-    const unsigned long long b = __ballot(pred);
-    unsigned r;
-    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(b) : "scc");
-    return r;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(pred);   // (HIP's __builtin_amdgcn_ballot_w64(int) costs a select and a compare)
+    asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(acc) : "s"(b) : "scc");
+    return acc;
 }
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
@@ -339,21 +340,21 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // The tables are padded with entries that always certify a miss (w = -inf), so groups of 4 need no bounds
 // handling and use immediate LDS offsets (the compiler packs the four independent chains into
 // v_pk_mul/fma_f32, two spheres per instruction).
+// Returns 16 acc + bits (entries are visited from the highest to the lowest).
 template <bool ANCH, bool SELF>
-__device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel)
+__device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel, unsigned acc)
 {
     static_assert(CULL_STRIDE == 4, "one 16-byte entry per (anchor, sphere)");
-    unsigned bits = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 3; u >= 0; --u) {
         asm volatile("" ::: "memory");                        // one entry in flight (registers decide occupancy)
         const f4 e = base[u];
         bool culled;
         if constexpr (ANCH) culled = cull_anchored(e, q); else culled = cull_origin(e, q);
         if constexpr (SELF) culled = culled || (u == jsel);   // the sphere this lane's shadow ray starts on
-        bits |= (unsigned)any_lane(!culled) << u;
+        acc = push_any_lane(acc, !culled);
     }
-    return bits;
+    return acc;
 }
 
 // Phase 1 of a scene query for the chunk of spheres [k0, k0+n), k0 a multiple of 64: one bit per sphere, set
@@ -371,18 +372,18 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
         lds_cf4 *cbase = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0);
         unsigned cm = 0;
-        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1) << j;
+        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
             cm &= cm - 1u;
             const int jb = c * CLUSTER;
-            const unsigned lo = cull4<ANCH, SELF>(sbase + jb, q, selfj - jb);
-            const unsigned hi = cull4<ANCH, SELF>(sbase + jb + 4, q, selfj - jb - 4);
-            mask |= (unsigned long long)(lo | (hi << 4)) << jb;
+            const unsigned hi = cull4<ANCH, SELF>(sbase + jb + 4, q, selfj - jb - 4, 0u);
+            const unsigned lohi = cull4<ANCH, SELF>(sbase + jb, q, selfj - jb, hi);
+            mask |= (unsigned long long)lohi << jb;
         }
     } else {
         const int npad = pad4(n);
-        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j) << j;
+        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
     }
     return mask;
 }
@@ -393,11 +394,11 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
     RayF q = make_rayf_dir(R);
     if (anchor >= 0) {
         const bool cand = self >= k0 && self < k0 + n;                        // per lane
-        if (__ballot(cand) != 0ull) {                                         // only shadow rays leaving a sphere
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {                                         // only shadow rays leaving a sphere
             add_origin(q, o, extent2);
             const float *cs = lds.sph32 + 4 * self;
             const bool self_culled = cand ? cull_origin(f4{cs[0], cs[1], cs[2], cs[3]}, q) : false;
-            if (__ballot(self_culled) != 0ull)
+            if (__builtin_amdgcn_ballot_w64(self_culled) != 0ull)
                 return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1);
         }
         return cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1);
@@ -515,7 +516,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
     for (int k0 = 0; k0 < S; k0 += 64) {
-      if (__ballot(!occ) == 0ull) break;
+      if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
@@ -525,7 +526,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
       while (mask) {
-        if (__ballot(!occ) == 0ull) break;                    // every live lane already occluded
+        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
         if (!occ) {
@@ -555,7 +556,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
     }
     const double *pl = lds.rec + S * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {
-        if (__ballot(!occ) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         if (!occ) {
             const double *g = pl + k * PL_STRIDE;
             double den, num;
@@ -640,7 +641,7 @@ __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool aliv
     Park3<PARK> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
     for (int b = 0; b <= p.depth; ++b) {
-        if (__ballot(alive) == 0ull) break;                                   // wave-uniform exit
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;                                   // wave-uniform exit
         V3 rgb;
         trace_bounce<PARK>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
         if (b == 0) acc.set(rgb);                                             // :120
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
         // PARK.  The same loop serves the build-defined stochastic mode (p.aa == 2): p.spp jittered samples.
         const bool stoch = (p.aa == 2);
         const bool interior = !stoch && inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
-        const int ntaps = stoch ? p.spp : ((__ballot(interior) != 0ull) ? 9 : 1);
+        const int ntaps = stoch ? p.spp : ((__builtin_amdgcn_ballot_w64(interior) != 0ull) ? 9 : 1);
         // neighbour offsets (dx,dy)+1 packed 2 bits each, in the order of kernels.py:53:
         // left, right, top(y+1), bottom(y-1), top-left, top-right, bottom-left, bottom-right
         constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;
