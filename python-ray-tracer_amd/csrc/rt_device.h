@@ -311,17 +311,38 @@ __device__ __forceinline__ bool cull_origin(const f4 c, const RayF &q)
     const float D = __builtin_fmaf(s, s, -cc);
     const float mg = __builtin_fmaf(CULL_K_ORIGIN, (ll + q.oo) + c[3], q.floorq);
     const float es = CULL_K_S * ((1.0f + ll) + q.oo);
-    return (D < -mg) || (s > es && cc > mg);
+    // no short-circuit: a divergent branch here costs an exec-mask region plus a select and a compare to get the
+    // result back into a lane mask
+    return (bool)((int)(D < -mg) | ((int)(s > es) & (int)(cc > mg)));
 }
 
-// acc = 2 acc + (some live lane's predicate holds) — decided and kept on the scalar unit in two instructions (a C
-// expression on the ballot word is lowered through v_cndmask + v_readfirstlane; compare + select + shift + or is
-// four).  Each CU has ONE scalar ALU for its four SIMDs and this kernel keeps it ~70 % busy, so scalar
-// instructions are not free here: the cull's mask building is its largest share.
-__device__ __forceinline__ unsigned push_any_lane(unsigned acc, bool pred)
+// Lane masks of the cull are produced by the compares themselves (inline asm, one VALU instruction each, result in
+// an SGPR pair, zero for inactive lanes), combined on the scalar unit and pushed into the accumulator with
+// s_cmp + s_addc:  acc = 2 acc + (some live lane holds no certificate).  Going through bool and a ballot instead
+// costs a v_cndmask and a v_cmp per sphere whenever the predicate is more than a single compare, and
+// compare + select + shift + or is four scalar instructions where two do.  Each CU has ONE scalar ALU for its four
+// SIMDs and this kernel keeps it well over half busy, so scalar instructions are not free here.
+// All of these are "not ..." compares: an unordered operand (NaN) yields 1 = no certificate.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask m_nlt_abs(float a, float b)   // !(|a| < b)
 {
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(pred);   // (HIP's __builtin_amdgcn_ballot_w64(int) costs a select and a compare)
-    asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(acc) : "s"(b) : "scc");
+    lanemask m; asm volatile("v_cmp_nlt_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b)); return m;
+}
+__device__ __forceinline__ lanemask m_nlt_neg(float a, float b)   // !(a < -b)
+{
+    lanemask m; asm volatile("v_cmp_nlt_f32_e64 %0, %1, -%2" : "=s"(m) : "v"(a), "v"(b)); return m;
+}
+__device__ __forceinline__ lanemask m_ngt(float a, float b)       // !(a > b)
+{
+    lanemask m; asm volatile("v_cmp_ngt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m;
+}
+__device__ __forceinline__ lanemask m_ne(int a, int b)            // a != b
+{
+    lanemask m; asm volatile("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b)); return m;
+}
+__device__ __forceinline__ unsigned push_any(unsigned acc, lanemask m)
+{
+    asm volatile("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(acc) : "s"(m) : "scc");
     return acc;
 }
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -349,10 +370,22 @@ __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel
     for (int u = 3; u >= 0; --u) {
         asm volatile("" ::: "memory");                        // one entry in flight (registers decide occupancy)
         const f4 e = base[u];
-        bool culled;
-        if constexpr (ANCH) culled = cull_anchored(e, q); else culled = cull_origin(e, q);
-        if constexpr (SELF) culled = culled || (u == jsel);   // the sphere this lane's shadow ray starts on
-        acc = push_any_lane(acc, !culled);
+        lanemask open;                                        // live lanes without a certificate for this entry
+        if constexpr (ANCH) {
+            const float sd = __builtin_fmaf(e[2], q.R.z, __builtin_fmaf(e[1], q.R.y, e[0] * q.R.x));
+            open = m_nlt_abs(sd, e[3]);                       // cull_anchored()
+        } else {                                              // cull_origin()
+            const float lx = q.o.x - e[0], ly = q.o.y - e[1], lz = q.o.z - e[2];
+            const float sd = __builtin_fmaf(lz, q.R.z, __builtin_fmaf(ly, q.R.y, lx * q.R.x));
+            const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+            const float cc = ll - e[3];
+            const float D = __builtin_fmaf(sd, sd, -cc);
+            const float mg = __builtin_fmaf(CULL_K_ORIGIN, (ll + q.oo) + e[3], q.floorq);
+            const float es = CULL_K_S * ((1.0f + ll) + q.oo);
+            open = m_nlt_neg(D, mg) & (m_ngt(sd, es) | m_ngt(cc, mg));
+        }
+        if constexpr (SELF) open &= m_ne(jsel, u);            // the sphere this lane's shadow ray starts on
+        acc = push_any(acc, open);
     }
     return acc;
 }
