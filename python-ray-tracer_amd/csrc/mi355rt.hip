@@ -39,6 +39,7 @@ struct rt_ctx {
     int w = 0, h = 0;
     double px = 0, y0 = 0, dy = 0, z0 = 0, dz = 0;
     size_t lds_limit_set = 0;
+    unsigned plane_codes = 0;         // axis codes of planes 0..3 (rt_device.h: KParams::plane_codes)
     unsigned *tile_stats = nullptr;   // caller-owned device buffer or NULL
     // Scheduler feedback: a launch files its tile blocks by cost; a small kernel behind it (same stream) turns
     // that into the dispatch order of the next launch.  (Running that kernel on a side stream, overlapped with
@@ -119,7 +120,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.tile_cycles = ctx->tile_stats;
     k.plane_stride = plane_stride;
     k.w = ctx->w; k.h = ctx->h; k.x0 = x0; k.x1 = x1;
-    k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth; k.NC = ctx->NC;
+    k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth; k.NC = ctx->NC; k.plane_codes = ctx->plane_codes;
     k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0; k.u8_hwc = (p->flags & RT_FLAG_U8_HWC) ? 1 : 0;
     k.spp = p->spp; k.seed = p->seed;
     k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
@@ -324,6 +325,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         std::vector<double> rec((size_t)S * rt::SPH_STRIDE + (size_t)P * rt::PL_STRIDE + (size_t)L * rt::LT_STRIDE +
                                 (size_t)NC * rt::CL_STRIDE + 1, 0.0);
         double *sp = rec.data();
+        unsigned codes = 0;
         for (int slot = 0; slot < S; ++slot, sp += rt::SPH_STRIDE) {
             const int k = order[slot];
             sp[7] = (double)k;                                   // the caller's index of this sphere
@@ -343,6 +345,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
                 int axis = -1, nonzero = 0;
                 for (int i = 0; i < 3; ++i) if (nraw[i] != 0.0f) { ++nonzero; axis = i; }
                 sp[15] = (nonzero == 1 && (nraw[axis] == 1.0f || nraw[axis] == -1.0f)) ? (double)(axis + 1) * (double)nraw[axis] : 0.0;
+                if (k < 4) codes |= (unsigned)(unsigned char)(signed char)sp[15] << (8 * k);
             }
             for (int i = 0; i < 3; ++i) {
                 sp[6 + i] = (double)nf[i];
@@ -373,6 +376,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         if (rc != RT_OK) return rc;
         RT_HIP(ctx, hipMemcpyAsync(ctx->scene.p, rec.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // rec is about to go out of scope
+        ctx->plane_codes = codes;
     } catch (const std::bad_alloc &) {
         return fail(ctx, RT_ERR_ALLOC, "out of host memory");
     }

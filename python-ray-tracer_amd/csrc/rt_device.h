@@ -73,7 +73,10 @@ struct KParams {
     long long plane_stride;    // elements between colour planes of the output
     int w, h, x0, x1;
     int S, P, L, depth;
-    int NC, pad2;              // sphere clusters (0 = flat)
+    int NC;                    // sphere clusters (0 = flat)
+    unsigned plane_codes;      // axis codes of planes 0..3, one signed byte each: 0 = general normal, +-(axis+1) = exactly
+                               // axis-aligned unit normal.  A kernel argument lives in an SGPR, so the plane tests of
+                               // the usual scenes (a floor, a wall) branch on the scalar unit without touching the VALU
     int aa, u8_rgb, tiles_y, ntiles;
     int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
     unsigned seed;             // jitter hash seed (stochastic AA)
@@ -454,22 +457,26 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
 // normal is exactly +-e_i (the reference's ground plane is (0,0,1)) has den = +-d_i and num = +-(p0_i - o_i)
 // bit for bit — the other two products are +-0 and add nothing — so 8 of the 13 operations are skipped under a
 // wave-uniform branch on the record's axis code (set by the host).
-__device__ __forceinline__ void plane_den_num(const double *__restrict__ g, const V3 &o, const V3 &d, double &den, double &num)
+// axis code of plane k from the kernel argument (planes 4.. use the general formula, which is exact for them too)
+__device__ __forceinline__ int plane_code(const KParams &p, int k)
 {
-    const double code = g[15];
-    if (code == 0.0) {
+    return k < 4 ? (int)(signed char)(p.plane_codes >> (8 * k)) : 0;
+}
+
+__device__ __forceinline__ void plane_den_num(const double *__restrict__ g, int code, const V3 &o, const V3 &d, double &den, double &num)
+{
+    if (code == 0) {
         const V3 n{g[3], g[4], g[5]};
         den = dot3(d, n);
         const V3 LP{g[0] - o.x, g[1] - o.y, g[2] - o.z};
         num = dot3(LP, n);
     } else {
-        const double a = __builtin_fabs(code);
+        const int a = code < 0 ? -code : code;
         double dc, lp;
-        if (a == 1.0)      { dc = d.x; lp = g[0] - o.x; }
-        else if (a == 2.0) { dc = d.y; lp = g[1] - o.y; }
-        else               { dc = d.z; lp = g[2] - o.z; }
-        den = code > 0.0 ? dc : -dc;
-        num = code > 0.0 ? lp : -lp;
+        if (a == 1)      { dc = d.x; lp = g[0] - o.x; }
+        else if (a == 2) { dc = d.y; lp = g[1] - o.y; }
+        else             { dc = d.z; lp = g[2] - o.z; }
+        if (code > 0) { den = dc; num = lp; } else { den = -dc; num = -lp; }
     }
 }
 
@@ -525,7 +532,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     for (int k = 0; k < P; ++k) {                             // intersections.py:41-68
         const double *g = pl + k * PL_STRIDE;
         double den, num;
-        plane_den_num(g, o, d, den, num);                     // :52, :59-61
+        plane_den_num(g, plane_code(p, k), o, d, den, num);   // :52, :59-61
         if (!(__builtin_fabs(den) < 0.001)) {                 // :55
             const double t = num / den;                       // :63
             if (best > t && t > 0.0) { best = t; idx = k; type = HIT_PLANE; }
@@ -593,7 +600,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         if (!occ) {
             const double *g = pl + k * PL_STRIDE;
             double den, num;
-            plane_den_num(g, o, d, den, num);
+            plane_den_num(g, plane_code(p, k), o, d, den, num);
             if (!(__builtin_fabs(den) < 0.001)) {
                 const double an = __builtin_fabs(num), ad = __builtin_fabs(den);
                 const bool same_sign = (num > 0.0 && den > 0.0) || (num < 0.0 && den < 0.0);

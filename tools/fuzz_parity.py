@@ -28,7 +28,7 @@ while time.time() - t0 < a.seconds:
     if kind == 2 and S > 0:      # one huge sphere
         sp[3, 0] = 40.0 * scale
     sp[4:7] = rng.integers(0, 256, (3, S))
-    P = int(rng.integers(0, 4))
+    P = int(rng.integers(0, 4)) if kind != 3 else int(rng.integers(1, 8))
     pl = np.zeros((9, P), np.float32)
     if P:
         pl[0:3] = rng.uniform(-3, 3, (3, P)) * scale
