@@ -11,7 +11,7 @@
 //   * the scene (float64-widened sphere/plane/light/material records, packed by the host) is
 //     staged once per workgroup into LDS and read with wave-uniform (broadcast) ds_reads;
 //   * every scene query normalises its direction ONCE (the reference re-normalises per sphere,
-//     intersections.py:13 — same value every time), with an exact integer/FMA shortcut for
+//     intersections.py:13 — same value every time), with an exact two-fma shortcut for
 //     already-unit vectors, and works on the quadratic scaled by 1/4 (exact in binary FP);
 //   * closest-hit keeps the smallest positive numerator and divides once per query;
 //   * shadow queries are any-hit: no sqrt/divide unless a decision is within rounding reach,
@@ -21,6 +21,10 @@
 //     float64 test can change anything; only spheres some lane might hit get the float64 test.
 //     The cull never decides a hit and never feeds a value into the result — it only skips
 //     float64 evaluations whose outcome (a miss) it has certified with an explicit error margin;
+//   * the kernel is bound by VALU instruction issue (~97 % of it on the headline config) with the CU's single
+//     scalar ALU as the second bound, so both instruction counts are what the code below economises: lane masks
+//     come straight from compares, the cull's mask is built with s_cmp + s_addc, table entries are one
+//     ds_read_b128 at an immediate offset of a VGPR-pinned base, wave-uniform facts travel in SGPRs;
 //   * no MFMA: there is no dense contraction on this path.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -58,7 +62,7 @@ constexpr int CLUSTER = 8;         // spheres per cluster
 #define RT_CLUSTER_MIN 96   // measured: flat wins at S=64 (1.62 vs 1.79 ms), clusters win at S=256 (27.9 vs 39.4 ms)
 #endif
 constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
-constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, w+margin (one ds_read_b128)
+constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, tau (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
 
 struct KParams {
@@ -361,9 +365,8 @@ __device__ __forceinline__ int order_bucket(unsigned c)
 __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTER : pad4(S); }
 
 // Certificates of 4 consecutive table entries -> 4 mask bits (bit u set = some live lane has no certificate).
-// The tables are padded with entries that always certify a miss (w = -inf), so groups of 4 need no bounds
-// handling and use immediate LDS offsets (the compiler packs the four independent chains into
-// v_pk_mul/fma_f32, two spheres per instruction).
+// The tables are padded with entries that always certify a miss (tau = +inf, r2 = -inf), so groups of 4 need no
+// bounds handling and use immediate LDS offsets.
 // Returns 16 acc + bits (entries are visited from the highest to the lowest).
 template <bool ANCH, bool SELF>
 __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel, unsigned acc)
