@@ -253,7 +253,7 @@ struct Lds {
 
 struct RayF {              // float32 shadow of a query, for the cull only
     F3 o, R;
-    float oo, floorq;
+    float mgq, esq;        // per-ray parts of the origin form's margins: K_O |o|² + floor,  K_S (1 + |o|²)
 };
 
 // The anchored form needs the direction only; the origin terms are added where the origin form is used.
@@ -262,14 +262,15 @@ __device__ __forceinline__ RayF make_rayf_dir(const V3 &R)
     RayF q;
     q.o = F3{0.0f, 0.0f, 0.0f};
     q.R = F3{(float)R.x, (float)R.y, (float)R.z};
-    q.oo = 0.0f; q.floorq = 0.0f;
+    q.mgq = 0.0f; q.esq = 0.0f;
     return q;
 }
 __device__ __forceinline__ void add_origin(RayF &q, const V3 &o, float extent2)
 {
     q.o = F3{(float)o.x, (float)o.y, (float)o.z};
-    q.oo = __builtin_fmaf(q.o.z, q.o.z, __builtin_fmaf(q.o.y, q.o.y, q.o.x * q.o.x));
-    q.floorq = CULL_K_FLOOR * (q.oo + extent2);
+    const float oo = __builtin_fmaf(q.o.z, q.o.z, __builtin_fmaf(q.o.y, q.o.y, q.o.x * q.o.x));
+    q.mgq = __builtin_fmaf(CULL_K_ORIGIN, oo, CULL_K_FLOOR * (oo + extent2));
+    q.esq = __builtin_fmaf(CULL_K_S, oo, CULL_K_S);
 }
 
 // tau of one (anchor, sphere) pair: the line through the anchor with unit direction R misses the sphere by more
@@ -316,8 +317,8 @@ __device__ __forceinline__ bool cull_origin(const f4 c, const RayF &q)
     const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
     const float cc = ll - c[3];
     const float D = __builtin_fmaf(s, s, -cc);
-    const float mg = __builtin_fmaf(CULL_K_ORIGIN, (ll + q.oo) + c[3], q.floorq);
-    const float es = CULL_K_S * ((1.0f + ll) + q.oo);
+    const float mg = __builtin_fmaf(CULL_K_ORIGIN, ll + c[3], q.mgq);
+    const float es = __builtin_fmaf(CULL_K_S, ll, q.esq);
     // no short-circuit: a divergent branch here costs an exec-mask region plus a select and a compare to get the
     // result back into a lane mask
     return (bool)((int)(D < -mg) | ((int)(s > es) & (int)(cc > mg)));
@@ -386,8 +387,8 @@ __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel
             const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
             const float cc = ll - e[3];
             const float D = __builtin_fmaf(sd, sd, -cc);
-            const float mg = __builtin_fmaf(CULL_K_ORIGIN, (ll + q.oo) + e[3], q.floorq);
-            const float es = CULL_K_S * ((1.0f + ll) + q.oo);
+            const float mg = __builtin_fmaf(CULL_K_ORIGIN, ll + e[3], q.mgq);
+            const float es = __builtin_fmaf(CULL_K_S, ll, q.esq);
             open = m_nlt_neg(D, mg) & (m_ngt(sd, es) | m_ngt(cc, mg));
         }
         if constexpr (SELF) open &= m_ne(jsel, u);            // the sphere this lane's shadow ray starts on
