@@ -17,6 +17,10 @@
  * exception crosses it (every function returns an rt_status).
  *
  * Threading: a context is not thread-safe; use one context per host thread / per GPU.
+ * Streams: rt_render_device may be called for one context on several streams (frames of a sequence in flight
+ * together); the scheduler feedback inside the context is safe under that use.  rt_set_camera and rt_set_raygen
+ * change host-side state only and apply to later launches; rt_set_scene and rt_set_pixel_loc rewrite device memory
+ * that launches in flight still read: wait for those launches (rt_stream_sync / rt_sync) before calling them.
  * The library has no CPU fallback: without a usable HIP device rt_create fails.
  */
 #ifndef MI355RT_H
