@@ -55,6 +55,22 @@ struct rt_ctx {
         std::vector<hipEvent_t> spare;
     } fb;
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
+    unsigned long long scene_epoch = 1;   // bumped by rt_set_scene only
+    // The float32 cull tables (rt::tables_kernel) of the last few (scene, camera position, floor) combinations.
+    // A set is built on the stream of the first launch that needs it; other streams wait for that build once;
+    // before a set is overwritten, the building stream waits for whatever the streams that read it have queued.
+    struct Tables {
+        Buf buf;
+        bool valid = false;
+        unsigned long long scene_epoch = 0, stamp = 0;
+        double cam[3] = {0, 0, 0};
+        float floor_anch = 0.0f;
+        int anchors = -1;
+        hipEvent_t built = nullptr;
+        std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
+    } tables[3];
+    unsigned long long table_stamp = 0;
+    std::vector<hipEvent_t> spare_events;
     std::string err;
 };
 
@@ -108,6 +124,65 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     return RT_OK;
 }
 
+int get_event(rt_ctx *ctx, hipEvent_t *ev)
+{
+    if (!ctx->spare_events.empty()) { *ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); return RT_OK; }
+    RT_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return RT_OK;
+}
+
+// The cull tables for this launch's scene / camera position / floor: reuse a built set or build one on `stream`.
+int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const float **out)
+{
+    rt_ctx::Tables *hit = nullptr, *victim = nullptr;
+    for (auto &t : ctx->tables) {
+        if (t.valid && t.scene_epoch == ctx->scene_epoch && t.anchors == k.anchors && t.floor_anch == k.floor_anch &&
+            std::memcmp(t.cam, k.cam_o, sizeof t.cam) == 0) { hit = &t; break; }
+        if (!victim || (!t.valid && victim->valid) || (t.valid == victim->valid && t.stamp < victim->stamp)) victim = &t;
+    }
+    if (hit) {
+        bool known = false;
+        for (auto &r : hit->readers) known = known || r.first == stream;
+        if (!known) {                                          // first use on this stream: the build must be complete
+            hipEvent_t ev = nullptr;
+            int rc = get_event(ctx, &ev);
+            if (rc != RT_OK) return rc;
+            hit->readers.emplace_back(stream, ev);
+            RT_HIP(ctx, hipStreamWaitEvent(stream, hit->built, 0));
+        }
+        hit->stamp = ++ctx->table_stamp;
+        *out = (const float *)hit->buf.p;
+        return RT_OK;
+    }
+    rt_ctx::Tables &t = *victim;
+    for (auto &r : t.readers) {                                // launches elsewhere may still read the set being replaced
+        if (r.first != stream) {
+            RT_HIP(ctx, hipEventRecord(r.second, r.first));
+            RT_HIP(ctx, hipStreamWaitEvent(stream, r.second, 0));
+        }
+        ctx->spare_events.push_back(r.second);
+    }
+    t.readers.clear();
+    t.valid = false;
+    const size_t bytes = rt::table_floats(k.S, k.NC, k.anchors) * sizeof(float);
+    int rc = ensure(ctx, t.buf, bytes ? bytes : 16);
+    if (rc != RT_OK) return rc;
+    if (!t.built) RT_HIP(ctx, hipEventCreateWithFlags(&t.built, hipEventDisableTiming));
+    hipLaunchKernelGGL(rt::tables_kernel, dim3(1), dim3(rt::WG_THREADS), 0, stream, k, (float *)t.buf.p);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipEventRecord(t.built, stream));
+    hipEvent_t ev = nullptr;
+    rc = get_event(ctx, &ev);
+    if (rc != RT_OK) return rc;
+    t.readers.emplace_back(stream, ev);
+    t.scene_epoch = ctx->scene_epoch; t.anchors = k.anchors; t.floor_anch = k.floor_anch;
+    std::memcpy(t.cam, k.cam_o, sizeof t.cam);
+    t.valid = true;
+    t.stamp = ++ctx->table_stamp;
+    *out = (const float *)t.buf.p;
+    return RT_OK;
+}
+
 int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_f32, int64_t plane_stride,
            hipStream_t stream)
 {
@@ -140,6 +215,10 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     {   // every ray origin of the launch lies within |cam| + 999 (depth + 1) of the world origin
         const double reach = std::sqrt(cam2) + 999.0 * (p->depth + 1) + std::sqrt(ctx->scene_extent2);
         k.floor_anch = (float)(0x1p-39 * reach * reach);
+    }
+    {
+        int rc = acquire_tables(ctx, k, stream, &k.ftab);
+        if (rc != RT_OK) return rc;
     }
     // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 6 workgroups per CU still
     // fit their LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
@@ -274,6 +353,12 @@ int rt_destroy(rt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->fb.hist, &ctx->fb.slot, &ctx->fb.order})
         if (b->p) (void)hipFree(b->p);
+    for (auto &t : ctx->tables) {
+        if (t.buf.p) (void)hipFree(t.buf.p);
+        if (t.built) (void)hipEventDestroy(t.built);
+        for (auto &r : t.readers) (void)hipEventDestroy(r.second);
+    }
+    for (hipEvent_t e : ctx->spare_events) (void)hipEventDestroy(e);
     for (auto &r : ctx->fb.readers) (void)hipEventDestroy(r.second);
     for (hipEvent_t e : ctx->fb.spare) (void)hipEventDestroy(e);
     if (ctx->fb.done) (void)hipEventDestroy(ctx->fb.done);
@@ -394,6 +479,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
     ctx->S = S; ctx->P = P; ctx->L = L; ctx->NC = nclusters;
     ctx->have_scene = true;
     ctx->epoch++;
+    ctx->scene_epoch++;
     return RT_OK;
 }
 
@@ -544,6 +630,11 @@ int rt_stream_destroy(rt_ctx *ctx, void *stream)
         else ++i;
     }
     if (f.stream == (hipStream_t)stream) f.stream = ctx->stream;   // its work is complete: anyone may take over
+    for (auto &t : ctx->tables)
+        for (size_t i = 0; i < t.readers.size();) {
+            if (t.readers[i].first == (hipStream_t)stream) { ctx->spare_events.push_back(t.readers[i].second); t.readers.erase(t.readers.begin() + (long)i); }
+            else ++i;
+        }
     RT_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
     return RT_OK;
 }

@@ -74,6 +74,7 @@ struct KParams {
     unsigned *hist;            // or nullptr: scheduler feedback, 1024 cost buckets (zero on entry)
     unsigned *slot;            // per tile block: (bucket << 20) | arrival rank within the bucket
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from the previous launch's costs
+    const float *ftab;         // the float32 cull tables of this scene / camera / depth, built once by tables_kernel
     long long plane_stride;    // elements between colour planes of the output
     int w, h, x0, x1;
     int S, P, L, depth;
@@ -748,6 +749,71 @@ __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anc
            (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + 16;   // + workgroup cost/arrival words
 }
 
+// floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table
+__host__ __device__ inline size_t table_floats(int S, int NC, int anchors)
+{
+    return (size_t)(1 + anchors) * (padS(S, NC) + pad4(NC)) * 4;
+}
+
+// The float32 cull tables (exact sphere table for the origin form; {A-c, tau} per anchor and sphere; the same two
+// for the cluster bounding spheres), in the order and layout the render kernel keeps them in LDS.  They depend on
+// the scene, the camera position (anchor 0) and floor_anch only, so the host runs this once per change of those
+// (one workgroup, a few microseconds) and every render workgroup copies the result.
+__global__ __launch_bounds__(WG_THREADS) void tables_kernel(const KParams p, float *__restrict__ out)
+{
+    const int nrec = (int)lds_doubles(p.S, p.P, p.L);
+    const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
+    float *sph32 = out;
+    float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
+    float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
+    float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
+    const double *rec = p.scene;
+    const float NINF = -__builtin_inff();
+    for (int k = threadIdx.x; k < Sp; k += WG_THREADS) {   // exact: the scene is float32
+        const double *g = rec + k * SPH_STRIDE;
+        const bool real = k < p.S;
+        sph32[4 * k + 0] = real ? (float)g[0] : 0.0f; sph32[4 * k + 1] = real ? (float)g[1] : 0.0f;
+        sph32[4 * k + 2] = real ? (float)g[2] : 0.0f; sph32[4 * k + 3] = real ? (float)g[3] : NINF;
+    }
+    const double *lt = rec + p.S * SPH_STRIDE + p.P * PL_STRIDE;
+    for (int e = threadIdx.x; e < p.anchors * Sp; e += WG_THREADS) {
+        const int a = e / Sp, k = e - a * Sp;
+        float *t = tab + (size_t)e * CULL_STRIDE;
+        if (k >= p.S) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }   // padding: always culled
+        const double *g = rec + k * SPH_STRIDE;
+        const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
+        const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
+        const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
+        const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
+        const double ll = lx * lx + ly * ly + lz * lz;
+        t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
+        t[3] = anchored_tau(ll, g[3], p.floor_anch);
+    }
+    // the same two tables for the cluster bounding spheres (float64 records after the lights; rounding the
+    // centre to float32 is covered by rounding R2 up)
+    const double *cl = rec + nrec;
+    for (int c = threadIdx.x; c < NCp; c += WG_THREADS) {
+        const bool real = c < p.NC;
+        const double *g = cl + (real ? c : 0) * CL_STRIDE;
+        csph32[4 * c + 0] = real ? (float)g[0] : 0.0f; csph32[4 * c + 1] = real ? (float)g[1] : 0.0f;
+        csph32[4 * c + 2] = real ? (float)g[2] : 0.0f;
+        csph32[4 * c + 3] = real ? (float)(g[3] * (1.0 + 0x1p-20)) : NINF;
+    }
+    for (int e = threadIdx.x; e < p.anchors * NCp; e += WG_THREADS) {
+        const int a = e / NCp, c = e - a * NCp;
+        float *t = ctab + (size_t)e * CULL_STRIDE;
+        if (c >= p.NC) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }
+        const double *g = cl + c * CL_STRIDE;
+        const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
+        const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
+        const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
+        const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
+        const double ll = lx * lx + ly * ly + lz * lz;
+        t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
+        t[3] = anchored_tau(ll, g[3], p.floor_anch);
+    }
+}
+
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
 template <bool AA, bool PARK>
@@ -770,59 +836,17 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
     float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
     unsigned *wgstat = reinterpret_cast<unsigned *>(ctab + (size_t)p.anchors * NCp * CULL_STRIDE);   // {cycles, waves done}
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
-    {   // stage the packed scene once per workgroup
+    {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
+        // used to be computed here, by every workgroup: 3 % of the frame's VALU instructions and a second barrier.)
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
-    }
-    __syncthreads();
 #if RT_PREFILTER
-    {   // float32 sphere table (exact: the scene is float32) and the anchored cull table
-        const float NINF = -__builtin_inff();
-        for (int k = threadIdx.x; k < Sp; k += WG_THREADS) {
-            const double *g = lds_raw + k * SPH_STRIDE;
-            const bool real = k < p.S;
-            sph32[4 * k + 0] = real ? (float)g[0] : 0.0f; sph32[4 * k + 1] = real ? (float)g[1] : 0.0f;
-            sph32[4 * k + 2] = real ? (float)g[2] : 0.0f; sph32[4 * k + 3] = real ? (float)g[3] : NINF;
-        }
-        const double *lt = lds_raw + p.S * SPH_STRIDE + p.P * PL_STRIDE;
-        for (int e = threadIdx.x; e < p.anchors * Sp; e += WG_THREADS) {
-            const int a = e / Sp, k = e - a * Sp;
-            float *t = tab + (size_t)e * CULL_STRIDE;
-            if (k >= p.S) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }   // padding: always culled
-            const double *g = lds_raw + k * SPH_STRIDE;
-            const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
-            const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
-            const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
-            const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
-            const double ll = lx * lx + ly * ly + lz * lz;
-            t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
-            t[3] = anchored_tau(ll, g[3], p.floor_anch);
-        }
-        // the same two tables for the cluster bounding spheres (float64 records in global memory, after the
-        // lights; rounding the centre to float32 is covered by rounding R2 up)
-        const double *cl = p.scene + nrec;
-        for (int c = threadIdx.x; c < NCp; c += WG_THREADS) {
-            const bool real = c < p.NC;
-            const double *g = cl + (real ? c : 0) * CL_STRIDE;
-            csph32[4 * c + 0] = real ? (float)g[0] : 0.0f; csph32[4 * c + 1] = real ? (float)g[1] : 0.0f;
-            csph32[4 * c + 2] = real ? (float)g[2] : 0.0f;
-            csph32[4 * c + 3] = real ? (float)(g[3] * (1.0 + 0x1p-20)) : NINF;
-        }
-        for (int e = threadIdx.x; e < p.anchors * NCp; e += WG_THREADS) {
-            const int a = e / NCp, c = e - a * NCp;
-            float *t = ctab + (size_t)e * CULL_STRIDE;
-            if (c >= p.NC) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }
-            const double *g = cl + c * CL_STRIDE;
-            const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
-            const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
-            const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
-            const double lx = ax - g[0], ly = ay - g[1], lz = az - g[2];
-            const double ll = lx * lx + ly * ly + lz * lz;
-            t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
-            t[3] = anchored_tau(ll, g[3], p.floor_anch);
-        }
+        const int nf4 = (int)(table_floats(p.S, p.NC, p.anchors) / 4);
+        const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
+        f4 *dst = reinterpret_cast<f4 *>(sph32);
+        for (int i = threadIdx.x; i < nf4; i += WG_THREADS) dst[i] = src[i];
+#endif
     }
     __syncthreads();
-#endif
     const Lds lds{lds_raw, sph32, tab, csph32, ctab, p.NC, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -300,6 +300,40 @@ def test_frames_pipelined_over_streams(renderer):
             renderer.free(b)
 
 
+def test_moving_camera_over_streams(renderer, oracle):
+    """A different camera for every frame, frames queued on three streams without waiting: each camera position
+    needs its own cull tables (built by a small kernel on the launching stream, cached for the last few positions,
+    overwritten only behind events from the streams that read them).  Every frame must be its own oracle frame."""
+    from python_ray_tracer_amd.scene import Camera
+    g = load_frame("default_128_d3")
+    w = h = 64
+    cams = [Camera((w, h), [-2.0 + 0.4 * i, 0.3 * i - 0.5, 2.0 + 0.1 * i], [0, -30 + 3 * i, 5 * i], fov=45.0) for i in range(5)]
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), 3, 0)
+    refs = [oracle.render(w, h, c.position, c.rotation, g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
+                          float(g["refl"]), 3, False, raygen=c.raygen(), want=("u8",))["u8"] for c in cams]
+    renderer.set_scene(g["spheres"], g["lights"], g["planes"])
+    streams = [renderer.stream_create() for _ in range(3)]
+    nframes = 20
+    bufs = [renderer.malloc(3 * w * h) for _ in range(nframes)]
+    try:
+        for i in range(nframes):
+            c = cams[i % 5]
+            renderer.set_camera(c.position, c.rotation)
+            renderer.set_raygen(w, h, *c.raygen())
+            renderer.render_device(p, 0, w, bufs[i], None, w * h, stream=streams[i % 3])
+        for s_ in streams:
+            renderer.sync(s_)
+        for i in range(nframes):
+            got = np.empty((3, w, h), np.uint8)
+            renderer.d2h(got, bufs[i])
+            assert np.array_equal(got, refs[i % 5]), f"frame {i}"
+    finally:
+        for s_ in streams:
+            renderer.stream_destroy(s_)
+        for b in bufs:
+            renderer.free(b)
+
+
 def test_tile_stats(renderer):
     g = load_frame("default_128_d3")
     w, h, _ = _setup(renderer, g)
