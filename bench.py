@@ -18,6 +18,12 @@ import os
 import sys
 import time
 
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, counting the
+# default stream and every library-internal one; two of the bench's three render streams can land on the same
+# queue, where their frames serialise (measured: 0.112 instead of 0.108 ms per frame).  Ask for 8 queues before
+# the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -72,7 +78,7 @@ def main():
     import torch.distributed as dist
     import python_ray_tracer_amd as pkg
     from python_ray_tracer_amd import workloads
-    from python_ray_tracer_amd.distributed import slab_bounds, FrameGatherer
+    from python_ray_tracer_amd.distributed import slab_bounds
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -89,65 +95,37 @@ def main():
     params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"])
     x0, x1 = slab_bounds(w, world, rank)
     ws = x1 - x0
-    # Frames are queued round-robin on `--streams` torch-owned, non-default streams (default 3), each frame in flight
-    # with its own output buffers: one frame's last workgroups overlap the next frame's first, which a single
-    # in-order stream cannot do.  Every frame is rendered in full; `--streams 1` is the strictly serial variant.
-    # (A NULL stream handed to rt_render_device would select the context's private stream instead.)
-    # With N > 1 the uint8 slabs of `--frames-per-gather` consecutive frames travel to rank 0 in ONE gather (a
-    # collective costs tens of microseconds however small it is; a 240-column slab renders in less), issued on a
-    # separate stream, two exchanges in flight: batch i is gathered and assembled while batch i+1 renders.
+    # python_ray_tracer_amd.distributed.SequencePipeline does the choreography (tests/test_distributed_cpu.py runs the
+    # same class on gloo): frames are queued round-robin on `--streams` torch-owned, non-default streams (default 3),
+    # each frame in flight with its own output buffers, so that one frame's last workgroups overlap the next
+    # frame's first — a single in-order stream cannot do that; every frame is rendered in full, `--streams 1` is
+    # the strictly serial variant.  With N > 1 the uint8 slabs of `--frames-per-gather` consecutive frames travel
+    # to rank 0 in ONE gather (a collective costs tens of microseconds however small it is; a 240-column slab
+    # renders in less), issued on a separate stream, two exchanges in flight: batch i is gathered and assembled
+    # while batch i+1 renders.
+    from python_ray_tracer_amd.distributed import SequencePipeline
     NS = max(1, a.streams)
-    tstreams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    assert all(t.cuda_stream for t in tstreams), "expected non-default stream handles"
     use_gather = world > 1 or a.force_gather
     if a.force_gather and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     F = max(1, a.frames_per_gather) if use_gather else 1
-    SLOTS = 2 if use_gather else NS                     # exchanges in flight / frames in flight
-    slabs_u8 = [torch.zeros((F, 3, ws, h), dtype=torch.uint8, device=dev) for _ in range(SLOTS)]
-    slabs_f32 = [torch.zeros((F, 3, ws, h), dtype=torch.float32, device=dev) for _ in range(SLOTS)]
-    comm = torch.cuda.Stream(device=dev) if use_gather else None
-    gatherer = FrameGatherer(w, h, torch.uint8, dev, dist, dst=0, slots=SLOTS, batch=F) if use_gather else None
-    busy = [False] * SLOTS
     frame = None
 
-    def collect(s_):
+    def on_frames(first, frames, count):                # rank 0: a batch of assembled (3,w,h) frames
         nonlocal frame
-        with torch.cuda.stream(comm):                   # the gather's stream dependencies follow torch's current stream
-            f = gatherer.finish(s_)
-            if f is not None:
-                frame = f if F == 1 else f[0]
-        busy[s_] = False
+        frame = frames[count - 1]
+    pipe = SequencePipeline(w, h, ws, dev, dist if use_gather else None, dst=0, streams=NS, frames_per_gather=F,
+                            want_f32=True, on_frames=on_frames)
+    assert all(pipe.stream_handle(i) for i in range(NS)), "expected non-default stream handles"
 
-    def step(i, last):
-        nonlocal frame
-        ts = tstreams[i % NS]
-        if not use_gather:
-            b = i % NS
-            r.render_device(params, x0, x1, slabs_u8[b].data_ptr(), slabs_f32[b].data_ptr(), ws * h, ts.cuda_stream)
-            frame = slabs_u8[b][0]
-            return
-        s_, j = (i // F) % SLOTS, i % F
-        if j == 0 and busy[s_]:                         # the slot's slabs are reused: its exchange must have completed
-            collect(s_)
-            ev = comm.record_event()
-            for t_ in tstreams:
-                t_.wait_event(ev)
-        r.render_device(params, x0, x1, slabs_u8[s_][j].data_ptr(), slabs_f32[s_][j].data_ptr(), ws * h, ts.cuda_stream)
-        if j == F - 1 or last:                          # the batch is complete (or the sequence ends): one gather
-            for t_ in tstreams:
-                comm.wait_event(t_.record_event())
-            with torch.cuda.stream(comm):
-                gatherer.submit(slabs_u8[s_], s_)
-            busy[s_] = True
+    ptrs = {}                                           # tensor view -> device address, looked up once per buffer
 
-    def drain(n):                                       # n = frames queued since the last drain (oldest slot first)
-        if use_gather:
-            cur = ((n - 1) // F) % SLOTS if n else 0
-            for s_ in [(cur + 1 + k) % SLOTS for k in range(SLOTS)]:
-                if busy[s_]:
-                    collect(s_)
+    def launch(u8, f32, stream):
+        k = id(u8)
+        if k not in ptrs:
+            ptrs[k] = (u8.data_ptr(), f32.data_ptr())
+        r.render_device(params, x0, x1, ptrs[k][0], ptrs[k][1], ws * h, stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -156,11 +134,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(2):                                  # setup, like the uploads above: the first two launches of a geometry
-        r.render_device(params, x0, x1, slabs_u8[0].data_ptr(), slabs_f32[0].data_ptr(), ws * h, tstreams[0].cuda_stream)
-    torch.cuda.synchronize()                            # measure tile costs and build the dispatch order
+        launch(pipe.u8v[0][0], pipe.f32v[0][0], pipe.stream_handle(0))
+    torch.cuda.synchronize()                            # build the cull tables, measure tile costs, build the dispatch order
     for i in range(a.warmup):
-        step(i, i == a.warmup - 1)
-    drain(a.warmup)
+        pipe.submit(launch)
+    pipe.drain()
     # One HIP event pair per launch stream around the whole timed region: elapsed / (launches on that stream) is
     # the mean duration of one launch as rocprofv3's kernel trace sees it (launches on one stream run back to back;
     # with N > 1 it also holds whatever waiting for a free slab costs) — NS of them are in flight at a time.
@@ -168,18 +146,22 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     fence()
     t0 = time.perf_counter()
+    first_pos = pipe.n
     for s_ in range(NS):
-        ev0[s_].record(tstreams[s_])
+        ev0[s_].record(pipe.streams[s_])
     for i in range(a.steps):
-        step(i, i == a.steps - 1)
+        pipe.submit(launch)
+    t_submitted = time.perf_counter()
     for s_ in range(NS):
-        ev1[s_].record(tstreams[s_])
-    drain(a.steps)                                      # every one of the K frames is assembled on rank 0
+        ev1[s_].record(pipe.streams[s_])
+    pipe.drain()                                        # every one of the K frames is assembled on rank 0
     fence()
     dt = time.perf_counter() - t0
-    launches = [len(range(s_, a.steps, NS)) for s_ in range(NS)]
+    launches = [sum(1 for i in range(first_pos, first_pos + a.steps) if i % NS == s_) for s_ in range(NS)]
     spans = [ev0[s_].elapsed_time(ev1[s_]) / launches[s_] for s_ in range(NS) if launches[s_]]
     kernel_ms = sum(spans) / max(len(spans), 1)
+    if not use_gather:
+        frame = pipe.last_slab()
 
     t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -221,6 +203,7 @@ def main():
                        "streams": NS,
                        "parallelism": f"column slabs x{world}, frames queued round-robin on {NS} stream(s)" + (f", one RCCL gather of the uint8 slabs of {F} frames to rank 0 per {F} steps, overlapped with the next steps' renders" if use_gather else "")},
             "frame_ms": round(ms_per_step, 5), "frame_latency_ms": round(kernel_ms_max, 5),
+            "host_submit_ms_per_step": round((t_submitted - t0) / a.steps * 1e3, 5),
             "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
             "frame_matches_reference_sha256": check,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -183,3 +183,65 @@ def test_batched_gather(tmp_path, oracle, world, case, batch, nframes):
         ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
                             raygen=raygen_closed_form(w, h, float(g["fov"])), want=("u8",))["u8"]
         assert np.array_equal(got[f"f{i}"], ref), f"frame {i}"
+
+
+def _sequence_worker(rank, world, port, batch, nframes, drains, out_path):
+    """SequencePipeline on CPU (gloo): the slot/batch bookkeeping bench.py relies on, with drains in the middle."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from python_ray_tracer_amd.distributed import slab_bounds, SequencePipeline
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = load_frame("c1_128")
+    w, h = 128, 128
+    x0, x1 = slab_bounds(w, world, rank)
+    got = {}
+
+    def on_frames(first, frames, count):
+        for j in range(count):
+            got[first + j] = frames[j].numpy().copy()
+    pipe = SequencePipeline(w, h, x1 - x0, torch.device("cpu"), dist, dst=0, streams=3, frames_per_gather=batch,
+                            want_f32=False, on_frames=on_frames)
+    for i in range(nframes):
+        def launch(u8, f32, stream, i=i):
+            assert f32 is None and stream is None and tuple(u8.shape) == (3, x1 - x0, h)
+            r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
+                           raygen=raygen_closed_form(w, h, 45.0), x0=x0, x1=x1, want=("u8",), nthreads=2)
+            u8.copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
+        pipe.submit(launch)
+        if i + 1 in drains:
+            pipe.drain()
+    pipe.drain()
+    if rank == 0:
+        assert sorted(got) == list(range(nframes)), sorted(got)
+        np.savez(out_path, **{f"f{i}": v for i, v in got.items()})
+    else:
+        assert not got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch,nframes,drains", [(3, 10, (4,)), (1, 4, ()), (4, 9, (2, 8))])
+def test_sequence_pipeline(tmp_path, oracle, batch, nframes, drains):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frames.npz")
+    mp.spawn(_sequence_worker, args=(2, _free_port(), batch, nframes, drains, out), nprocs=2, join=True)
+    got = np.load(out)
+    g = load_frame("c1_128")
+    refs = [oracle.render(128, 128, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, d, False,
+                          raygen=raygen_closed_form(128, 128, 45.0), want=("u8",))["u8"] for d in range(3)]
+    for i in range(nframes):
+        assert np.array_equal(got[f"f{i}"], refs[i % 3]), f"frame {i}"
+
+
+def test_sequence_pipeline_without_a_group():
+    """No process group: nothing is exchanged, frames cycle through per-stream buffers."""
+    import torch
+    from python_ray_tracer_amd.distributed import SequencePipeline
+    pipe = SequencePipeline(16, 8, 16, torch.device("cpu"), None, streams=3, want_f32=True)
+    for i in range(5):
+        pipe.submit(lambda u8, f32, stream, i=i: (u8.fill_(i), f32.fill_(float(i))))
+    pipe.drain()
+    assert int(pipe.last_slab()[0, 0, 0]) == 4 and pipe.index == 5
