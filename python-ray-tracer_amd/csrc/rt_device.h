@@ -33,8 +33,8 @@
 #pragma clang fp contract(off)
 
 // Build-time knobs (A/B builds for tools/ab_bench.py); the defaults are the measured best on MI355X:
-//   RT_PREFILTER        float32 cull in front of the float64 sphere tests            (C2 -10 %, C5 -50 %)
-//   RT_FAST_NORMALIZE   shared-reciprocal normalize instead of sqrt + three divisions (C2 -7 %)
+//   RT_PREFILTER        float32 cull in front of the float64 sphere tests            (C2 -23 %, C4 -63 %)
+//   RT_FAST_NORMALIZE   shared-reciprocal normalize instead of sqrt + three divisions (C2 -10 %)
 //   RT_WAVES_PER_WG     tiles (wavefronts) per workgroup: 4 beats 1, 2, 6 and 8 by 10-75 %
 //   RT_CLUSTER_MIN      sphere count above which the scene is stored in clusters of 8
 //   RT_W_PARK, RT_W_AAPARK  waves/SIMD the LDS-parked variants are compiled for
