@@ -124,6 +124,15 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     return RT_OK;
 }
 
+const void *kernel_variant(bool aa, bool park, int wpw)
+{
+    if (wpw == 2)
+        return aa ? (park ? (const void *)rt::render_kernel<true, true, 2> : (const void *)rt::render_kernel<true, false, 2>)
+                  : (park ? (const void *)rt::render_kernel<false, true, 2> : (const void *)rt::render_kernel<false, false, 2>);
+    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4> : (const void *)rt::render_kernel<true, false, 4>)
+              : (park ? (const void *)rt::render_kernel<false, true, 4> : (const void *)rt::render_kernel<false, false, 4>);
+}
+
 int get_event(rt_ctx *ctx, hipEvent_t *ev)
 {
     if (!ctx->spare_events.empty()) { *ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); return RT_OK; }
@@ -168,7 +177,7 @@ int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const 
     int rc = ensure(ctx, t.buf, bytes ? bytes : 16);
     if (rc != RT_OK) return rc;
     if (!t.built) RT_HIP(ctx, hipEventCreateWithFlags(&t.built, hipEventDisableTiming));
-    hipLaunchKernelGGL(rt::tables_kernel, dim3(1), dim3(rt::WG_THREADS), 0, stream, k, (float *)t.buf.p);
+    hipLaunchKernelGGL(rt::tables_kernel, dim3(1), dim3(rt::TABLE_THREADS), 0, stream, k, (float *)t.buf.p);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(t.built, stream));
     hipEvent_t ev = nullptr;
@@ -220,27 +229,31 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         int rc = acquire_tables(ctx, k, stream, &k.ftab);
         if (rc != RT_OK) return rc;
     }
-    // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 6 workgroups per CU still
-    // fit their LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
+    // Workgroup size: 2 tiles (wavefronts) for scenes whose LDS image (records + cull tables) is small, 4 otherwise
+    // (every workgroup stages its own copy; rt_device.h has the measurements).
+    // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 24 wavefronts per CU still
+    // fit their workgroups' LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
     const bool aa = k.aa != 0;
-    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true);
-    const bool park = lds_park * 6 <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false);
-    const void *fn = aa ? (park ? (const void *)rt::render_kernel<true, true> : (const void *)rt::render_kernel<true, false>)
-                        : (park ? (const void *)rt::render_kernel<false, true> : (const void *)rt::render_kernel<false, false>);
+    const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
+    const int wpw = image <= 3072 ? 2 : 4;
+    const int wgt = 64 * wpw;
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
+    const bool park = lds_park * (24 / wpw) <= 160 * 1024;
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt);
+    const void *fn = kernel_variant(aa, park, wpw);
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
-        for (const void *f : {(const void *)rt::render_kernel<true, true>, (const void *)rt::render_kernel<true, false>,
-                              (const void *)rt::render_kernel<false, true>, (const void *)rt::render_kernel<false, false>})
-            RT_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 8; ++v)
+            RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
     }
-    const unsigned grid = (unsigned)((k.ntiles + rt::WAVES_PER_WG - 1) / rt::WAVES_PER_WG);
+    const unsigned grid = (unsigned)((k.ntiles + wpw - 1) / wpw);
     // Scheduler feedback (longest-first dispatch): a launch files its tile blocks by cost and dispatches in the
     // order built from the previous measured launch of the same range, depth and AA mode.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
     const long long key = ((long long)x0 << 42) ^ ((long long)x1 << 21) ^ (long long)ctx->h ^ ((long long)k.aa << 62)
-                          ^ ((long long)k.depth << 56) ^ ((long long)(k.aa == RT_AA_STOCHASTIC ? k.spp : 0) << 48);
+                          ^ ((long long)k.depth << 56) ^ ((long long)(k.aa == RT_AA_STOCHASTIC ? k.spp : 0) << 48)
+                          ^ ((long long)wpw << 18);
     rt_ctx::Feedback &f = ctx->fb;
     // Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile
     // order, once from longest-first order): the costs are the same again, so the launch neither measures nor
@@ -292,7 +305,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         k.order = (f.key == key) ? (const unsigned *)f.order.p : nullptr;
     }
     void *args[] = {(void *)&k};
-    RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(rt::WG_THREADS), args, lds, stream));
+    RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(wgt), args, lds, stream));
     if (measure) {
         hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
                            (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid);
@@ -679,7 +692,7 @@ int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info)
     if (!info) return fail(ctx, RT_ERR_BAD_ARG, "info is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipFuncAttributes a;
-    RT_HIP(ctx, hipFuncGetAttributes(&a, (const void *)rt::render_kernel<false, true>));
+    RT_HIP(ctx, hipFuncGetAttributes(&a, (const void *)rt::render_kernel<false, true, 2>));
     hipDeviceProp_t prop;
     RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     std::memset(info, 0, sizeof *info);

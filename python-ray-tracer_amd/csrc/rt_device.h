@@ -35,7 +35,6 @@
 // Build-time knobs (A/B builds for tools/ab_bench.py); the defaults are the measured best on MI355X:
 //   RT_PREFILTER        float32 cull in front of the float64 sphere tests            (C2 -23 %, C4 -63 %)
 //   RT_FAST_NORMALIZE   shared-reciprocal normalize instead of sqrt + three divisions (C2 -10 %)
-//   RT_WAVES_PER_WG     tiles (wavefronts) per workgroup: 4 beats 1, 2, 6 and 8 by 10-75 %
 //   RT_CLUSTER_MIN      sphere count above which the scene is stored in clusters of 8
 //   RT_W_PARK, RT_W_AAPARK  waves/SIMD the LDS-parked variants are compiled for
 #ifndef RT_PREFILTER
@@ -48,11 +47,10 @@
 namespace rt {
 
 constexpr int TILE = 8;            // 8x8 pixels per wavefront
-#ifndef RT_WAVES_PER_WG
-#define RT_WAVES_PER_WG 4
-#endif
-constexpr int WAVES_PER_WG = RT_WAVES_PER_WG;
-constexpr int WG_THREADS = 64 * WAVES_PER_WG;
+// Tiles (wavefronts) per workgroup: a template parameter of the kernel, chosen per scene by the host.  Small
+// workgroups start and retire at a finer grain (C2: 2 waves beat 4 by 3 %); every workgroup stages its own copy
+// of the scene and its cull tables, so bigger scenes want bigger workgroups (C4: 4 waves beat 2 by 24 %, C5 by 69 %).
+constexpr int TABLE_THREADS = 256; // tables_kernel's workgroup
 constexpr int SPH_STRIDE = 8;      // doubles per sphere record: cx,cy,cz,r2, R,G,B, caller's index
 constexpr int PL_STRIDE = 16;      // ox,oy,oz,nx,ny,nz, Nx,Ny,Nz, bNx,bNy,bNz, R,G,B, axis code (0 general, +-1/2/3 = +-e_x/y/z)
 constexpr int LT_STRIDE = 4;       // x,y,z,pad
@@ -192,18 +190,18 @@ enum { HIT_NONE = 0, HIT_SPHERE = 1, HIT_PLANE = 2 };
 // are forwarded and the values stay in VGPRs; without the address space the accesses become flat).
 // Scenes whose LDS image is too large for 6+ workgroups per CU run the register variant (host picks).
 typedef __attribute__((address_space(3))) double lds_f64;
-template <bool PARK> struct Park3 {
+template <bool PARK, int WGT> struct Park3 {
     volatile lds_f64 *p;
     V3 v;
     __device__ __forceinline__ Park3(double *base, int slot)
-        : p((volatile lds_f64 *)base + slot * 3 * WG_THREADS + threadIdx.x), v{0.0, 0.0, 0.0} {}
+        : p((volatile lds_f64 *)base + slot * 3 * WGT + threadIdx.x), v{0.0, 0.0, 0.0} {}
     __device__ __forceinline__ void set(const V3 &a)
     {
-        if constexpr (PARK) { p[0] = a.x; p[WG_THREADS] = a.y; p[2 * WG_THREADS] = a.z; } else v = a;
+        if constexpr (PARK) { p[0] = a.x; p[WGT] = a.y; p[2 * WGT] = a.z; } else v = a;
     }
     __device__ __forceinline__ V3 get() const
     {
-        if constexpr (PARK) return V3{p[0], p[WG_THREADS], p[2 * WG_THREADS]}; else return v;
+        if constexpr (PARK) return V3{p[0], p[WGT], p[2 * WGT]}; else return v;
     }
 };
 
@@ -246,7 +244,7 @@ struct Lds {
     const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
     const float *ctab;     // anchors x NCp x CULL_STRIDE: cluster bounding spheres, anchored form
     int NC;
-    double *acc;           // 6 (9 with AA) x WG_THREADS doubles, [slot][thread] (consecutive lanes -> consecutive banks):
+    double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
                            // slots 0-2 the running colour of the current sample, 3-5 the incoming direction
                            // during the light loop, 6-8 (AA kernel only) the tap sums — kept out of VGPRs that would stay
                            // live across every query of every bounce (registers decide occupancy here)
@@ -623,7 +621,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
 
 // trace.py:44-112.  On entry `alive` lanes carry a ray (o,d); on exit `alive` is false for lanes
 // that missed (the reference's 404 sentinels), rgb is this bounce's colour, (o,d) the next ray.
-template <bool PARK>
+template <bool PARK, int WGT>
 __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                              V3 &o, V3 &d, V3 &rgb)
 {
@@ -654,7 +652,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         rgb = V3{p.amb * col(0), p.amb * col(1), p.amb * col(2)};             // :77 (0 + amb*col)
         Pt = V3{Pt.x + bN.x, Pt.y + bN.y, Pt.z + bN.z};                       // :82-83
         const int self = (type == HIT_SPHERE) ? idx : -1;
-        Park3<PARK> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
+        Park3<PARK, WGT> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
         dpark.set(d);
 
         const double *lt = lds.rec + S * SPH_STRIDE + P * PL_STRIDE;
@@ -680,15 +678,15 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 }
 
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
-template <bool PARK>
+template <bool PARK, int WGT>
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d)
 {
-    Park3<PARK> acc(lds.acc, 0);                                              // the running colour
+    Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
     for (int b = 0; b <= p.depth; ++b) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;                                   // wave-uniform exit
         V3 rgb;
-        trace_bounce<PARK>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
+        trace_bounce<PARK, WGT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
             const double wgt = p.refl_pow[b - 1];
@@ -740,12 +738,12 @@ __device__ __forceinline__ uint8_t clip_color(double c)
 
 // LDS image: [float64 records][per-thread slots 6|9 x 256 doubles][256 int32 pixel offsets][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
-__host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x WG_THREADS doubles
-__host__ __device__ inline int lds_offset_words(bool park) { return park ? WG_THREADS : 0; }    // + one int32 per thread: the pixel offset
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park)
+__host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x workgroup-size doubles
+__host__ __device__ inline int lds_offset_words(bool park, int wgt) { return park ? wgt : 0; }    // + one int32 per thread: the pixel offset
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt)
 {
-    return (lds_doubles(S, P, L) + lds_slots(aa, park) * WG_THREADS) * sizeof(double) +
-           ((size_t)lds_offset_words(park) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
+    return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
+           ((size_t)lds_offset_words(park, wgt) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
            (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + 16;   // + workgroup cost/arrival words
 }
 
@@ -759,7 +757,7 @@ __host__ __device__ inline size_t table_floats(int S, int NC, int anchors)
 // for the cluster bounding spheres), in the order and layout the render kernel keeps them in LDS.  They depend on
 // the scene, the camera position (anchor 0) and floor_anch only, so the host runs this once per change of those
 // (one workgroup, a few microseconds) and every render workgroup copies the result.
-__global__ __launch_bounds__(WG_THREADS) void tables_kernel(const KParams p, float *__restrict__ out)
+__global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, float *__restrict__ out)
 {
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
@@ -769,14 +767,14 @@ __global__ __launch_bounds__(WG_THREADS) void tables_kernel(const KParams p, flo
     float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
     const double *rec = p.scene;
     const float NINF = -__builtin_inff();
-    for (int k = threadIdx.x; k < Sp; k += WG_THREADS) {   // exact: the scene is float32
+    for (int k = threadIdx.x; k < Sp; k += TABLE_THREADS) {   // exact: the scene is float32
         const double *g = rec + k * SPH_STRIDE;
         const bool real = k < p.S;
         sph32[4 * k + 0] = real ? (float)g[0] : 0.0f; sph32[4 * k + 1] = real ? (float)g[1] : 0.0f;
         sph32[4 * k + 2] = real ? (float)g[2] : 0.0f; sph32[4 * k + 3] = real ? (float)g[3] : NINF;
     }
     const double *lt = rec + p.S * SPH_STRIDE + p.P * PL_STRIDE;
-    for (int e = threadIdx.x; e < p.anchors * Sp; e += WG_THREADS) {
+    for (int e = threadIdx.x; e < p.anchors * Sp; e += TABLE_THREADS) {
         const int a = e / Sp, k = e - a * Sp;
         float *t = tab + (size_t)e * CULL_STRIDE;
         if (k >= p.S) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }   // padding: always culled
@@ -792,14 +790,14 @@ __global__ __launch_bounds__(WG_THREADS) void tables_kernel(const KParams p, flo
     // the same two tables for the cluster bounding spheres (float64 records after the lights; rounding the
     // centre to float32 is covered by rounding R2 up)
     const double *cl = rec + nrec;
-    for (int c = threadIdx.x; c < NCp; c += WG_THREADS) {
+    for (int c = threadIdx.x; c < NCp; c += TABLE_THREADS) {
         const bool real = c < p.NC;
         const double *g = cl + (real ? c : 0) * CL_STRIDE;
         csph32[4 * c + 0] = real ? (float)g[0] : 0.0f; csph32[4 * c + 1] = real ? (float)g[1] : 0.0f;
         csph32[4 * c + 2] = real ? (float)g[2] : 0.0f;
         csph32[4 * c + 3] = real ? (float)(g[3] * (1.0 + 0x1p-20)) : NINF;
     }
-    for (int e = threadIdx.x; e < p.anchors * NCp; e += WG_THREADS) {
+    for (int e = threadIdx.x; e < p.anchors * NCp; e += TABLE_THREADS) {
         const int a = e / NCp, c = e - a * NCp;
         float *t = ctab + (size_t)e * CULL_STRIDE;
         if (c >= p.NC) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }
@@ -816,20 +814,21 @@ __global__ __launch_bounds__(WG_THREADS) void tables_kernel(const KParams p, flo
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
-template <bool AA, bool PARK>
+template <bool AA, bool PARK, int WPW>
 #ifndef RT_W_PARK
 #define RT_W_PARK 7
 #endif
 #ifndef RT_W_AAPARK
 #define RT_W_AAPARK 5
 #endif
-__global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
+__global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
+    constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
     extern __shared__ double lds_raw[];
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     double *accum = lds_raw + nrec;
     int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK) * WG_THREADS);
-    float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK));
+    float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK, WG_THREADS));
     const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
     float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
     float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
@@ -871,7 +870,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
     const V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]};                           // kernels.py:16
     double R, G, B;
     if constexpr (!AA) {
-        const V3 c = sample<PARK>(lds, p, inb, o, primary_dir(p, pixel_P(p, xc, yc)));   // kernels.py:19-26
+        const V3 c = sample<PARK, WG_THREADS>(lds, p, inb, o, primary_dir(p, pixel_P(p, xc, yc)));   // kernels.py:19-26
         R = c.x; G = c.y; B = c.z;
     } else {
         // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
@@ -883,7 +882,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
         // neighbour offsets (dx,dy)+1 packed 2 bits each, in the order of kernels.py:53:
         // left, right, top(y+1), bottom(y-1), top-left, top-right, bottom-left, bottom-right
         constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;
-        Park3<PARK> taps(lds.acc, 2);
+        Park3<PARK, WG_THREADS> taps(lds.acc, 2);
 #pragma unroll 1
         for (int tap = 0; tap < ntaps; ++tap) {
             const V3 Pp = pixel_P(p, xc, yc);                                 // :19
@@ -899,7 +898,7 @@ __global__ __launch_bounds__(WG_THREADS, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK 
                 const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
                 Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
             }
-            const V3 s = sample<PARK>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt));   // :26 / :56
+            const V3 s = sample<PARK, WG_THREADS>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt));   // :26 / :56
             if (tap == 0) taps.set(s);
             else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.y, a.z + s.z}); }
             else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.z, a.z + s.y}); }   // :58-60 (G += B_s; B += G_s)
