@@ -235,7 +235,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     // fit their workgroups' LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
     const bool aa = k.aa != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    const int wpw = image <= 3072 ? 2 : 4;
+    const int wpw = image <= 4608 ? 2 : 4;      // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
     const bool park = lds_park * (24 / wpw) <= 160 * 1024;
