@@ -10,6 +10,7 @@ import os
 import statistics
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # --streams: keep the streams on distinct hardware queues (see bench.py)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
