@@ -819,7 +819,7 @@ template <bool AA, bool PARK, int WPW>
 #define RT_W_PARK 7
 #endif
 #ifndef RT_W_AAPARK
-#define RT_W_AAPARK 5
+#define RT_W_AAPARK 7   // 72 VGPRs with a few spills (76 B/lane of scratch) still beat 5 waves/SIMD without: -9 %
 #endif
 __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
