@@ -7,9 +7,10 @@
 //
 // How it is organised is not the reference's one-thread-per-pixel translation:
 //   * a 64-lane wavefront owns an 8x8 tile (8 consecutive y per x-row = the contiguous
-//     direction of the (3,w,h) frame); 4 waves per workgroup take 4 tiles consecutive in y;
-//   * the scene (float64-widened sphere/plane/light/material records, packed by the host) is
-//     staged once per workgroup into LDS and read with wave-uniform (broadcast) ds_reads;
+//     direction of the (3,w,h) frame); the 2 or 4 waves of a workgroup take tiles consecutive in y;
+//   * the scene (float64-widened sphere/plane/light/material records, packed by the host) and its float32 cull
+//     tables (built once per scene/camera by tables_kernel) are copied once per workgroup into LDS and read
+//     with wave-uniform (broadcast) ds_reads;
 //   * every scene query normalises its direction ONCE (the reference re-normalises per sphere,
 //     intersections.py:13 — same value every time), with an exact two-fma shortcut for
 //     already-unit vectors, and works on the quadratic scaled by 1/4 (exact in binary FP);
