@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 #define RT_MAX_DEPTH 16      /* entries of rt_params.refl_pow (reflection bounces) */
 #define RT_MAX_SPHERES 1024  /* scene limits: the packed scene must fit one workgroup's LDS */
 #define RT_MAX_PLANES 64
@@ -76,6 +76,9 @@ typedef enum rt_status {
                                 order is kept and measuring stops until an rt_set_* call or another
                                 range/depth/mode/stream starts it again */
 
+#define RT_FLAG_COUNT_RAYS 16 /* run the counting instantiation of the kernel (slower: registers instead of LDS-parked
+                                state): adds this launch's ray counts to the context's rt_stats.  Same pixels. */
+
 typedef struct rt_ctx rt_ctx;
 
 /* Shader scalars of the launch (main.py:11, kernels.py:7 args amb, lamb, refl, refl_depth, aliasing).
@@ -103,6 +106,24 @@ typedef struct rt_kernel_info {
     int32_t clock_khz;
     int32_t reserved;
 } rt_kernel_info;
+
+/* What the context has done since rt_create / rt_reset_stats (SURVEY.md §5 "metrics": rays counted).
+ * The ray counters are those of launches made with RT_FLAG_COUNT_RAYS, in the reference's terms:
+ *   closest_queries = calls of get_intersection for a closest hit (trace.py:53), hits = those that hit,
+ *   shadow_traced + shadow_skipped = shadow queries the reference issues (trace.py:92, one per light and hit);
+ *   skipped ones are those whose answer the reference discards (Lambert term <= 0, trace.py:101): the kernel does
+ *   not trace them.  With RT_AA_REFERENCE the kernel traces every lattice sample once where the reference
+ *   re-traces shared taps, so its counts are lower than the reference algorithm's. */
+typedef struct rt_stats {
+    uint64_t launches;            /* render launches */
+    uint64_t launches_measuring;  /* ... that timed their tiles and rebuilt the dispatch order */
+    uint64_t launches_settled;    /* ... that dispatched in a settled (kept) order */
+    uint64_t table_builds;        /* cull-table sets built (one per new scene / camera position / depth bound) */
+    uint64_t closest_queries;
+    uint64_t hits;
+    uint64_t shadow_traced;
+    uint64_t shadow_skipped;
+} rt_stats;
 
 int rt_abi_version(void);
 
@@ -171,6 +192,11 @@ int rt_sync(rt_ctx *ctx);
 int rt_stream_create(rt_ctx *ctx, void **stream);
 int rt_stream_destroy(rt_ctx *ctx, void *stream);
 int rt_stream_sync(rt_ctx *ctx, void *stream);   /* NULL = context stream */
+/* A stream the caller owns (a torch / HIP stream passed to rt_render_device) must be forgotten before its owner
+ * destroys it: the context keeps the handles of streams that launched on it, to fence them when the dispatch order
+ * or a cull-table set they may still read is rebuilt.  Waits for the stream's queued work, then drops the handle;
+ * the stream may be used with the context again afterwards.  rt_stream_destroy does this by itself. */
+int rt_stream_forget(rt_ctx *ctx, void *stream);
 
 /* hipEvent pair on `stream` (NULL = context stream) around whatever is launched in between;
  * rt_timer_end synchronises on the second event and returns elapsed milliseconds. */
@@ -178,6 +204,10 @@ int rt_timer_begin(rt_ctx *ctx, void *stream);
 int rt_timer_end(rt_ctx *ctx, void *stream, float *ms);
 
 int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info);
+
+/* rt_get_stats waits for the device when counting launches have been made (the counters live in device memory). */
+int rt_get_stats(rt_ctx *ctx, rt_stats *stats);
+int rt_reset_stats(rt_ctx *ctx);
 
 /* Statistics: with a non-NULL device buffer of ceil((x1-x0)/8) * ceil(h/8) uint32, every later launch stores
  * the shader-clock cycles each 8x8 tile's wavefront took, tile index = tile_x * ceil(h/8) + tile_y

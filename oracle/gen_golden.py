@@ -385,6 +385,117 @@ def gen_host_helpers(mods):
     print(f"  wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)", flush=True)
 
 
+# ----------------------------------------------------------------------------- closest-hit tie rule
+def _norm3(v):
+    n = np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+    return np.stack([v[0] / n, v[1] / n, v[2] / n])
+
+
+def _numerators(o, R, a, spheres):
+    """Per sphere, the numerator n = -b/2 -/+ sqrt(disc/4) and the reference's distance t = n / a (the quadratic
+    of intersections.py:19-36 divided by 4, which is exact), for rays (o[:, j], R) — plain float64 numpy, no FMA."""
+    N, T = [], []
+    for k in range(spheres.shape[1]):
+        c = spheres[0:3, k].astype(np.float64)
+        r2 = np.float64(np.float32(spheres[3, k]) * np.float32(spheres[3, k]))
+        L0, L1, L2 = o[0] - c[0], o[1] - c[1], o[2] - c[2]
+        s = (L0 * R[0] + L1 * R[1]) + L2 * R[2]
+        cc = ((L0 * L0 + L1 * L1) + L2 * L2) - r2
+        D = s * s - a * cc
+        ok = D >= 0
+        q = np.sqrt(np.where(ok, D, 0))
+        n = -s - q
+        n = np.where(n > 0, n, -s + q)
+        hit = ok & (n > 0)
+        N.append(np.where(hit, n, np.inf))
+        T.append(np.where(hit, n / a, np.inf))
+    return np.array(N), np.array(T)
+
+
+def find_tie_cases(ncases=6, K=16, side=8):
+    """Scenes in which two spheres have DIFFERENT numerators that round to the SAME distance t, so that the
+    reference's rule (smallest t, then lowest index: trace.py:26) and "smallest numerator" disagree.
+
+    Construction: K concentric spheres of radius 4 around the world origin whose centres differ by a fraction of an
+    ulp-sized step in y (sphere 0 has the largest offset), the camera a few 2^-52 from the centre: every ray leaves
+    through the far side with numerator n = q - s within a few ulp of 4.  For a ray with a = R.R = 1 - 2^-52 the
+    numerators 4 - 1ulp and 4 - 2ulp both give t = 4.0; with R.y > 0 the lower index has the larger numerator.
+    The pixel grid is explicit (rt_set_pixel_loc): `side`^2 primary-ray targets picked from a 1024x1024 camera grid
+    for having a <= 1 - 2^-52, and the camera offset is scanned for the position with the most disagreeing pixels."""
+    w = h = 1024
+    px = float(1 / np.tan(np.radians(45.0) / 2))
+    X, Y = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+    P = np.stack([np.full((w, h), px), X * ((-1 - 1) / float(w - 1)) + 1, Y * ((-1 - 1) / float(h - 1)) + 1])
+    d = _norm3(P)                        # camera rotation = identity: matmul(I, P) = P exactly
+    R = _norm3(d)
+    a = (R[0] * R[0] + R[1] * R[1]) + R[2] * R[2]
+    sel = np.argwhere((a <= 1 - 2.0 ** -52) & (R[1] > 0.05))
+    rng = np.random.default_rng(2026)
+    spheres = np.zeros((7, K), np.float32)
+    spheres[3] = 4.0
+    spheres[1] = (np.arange(K)[::-1] - K // 2) * 2e-16
+    spheres[4] = 5 + 10 * np.arange(K)
+    spheres[5] = 250 - 10 * np.arange(K)
+    spheres[6] = 37 + 3 * np.arange(K)
+    cases = []
+    for attempt in range(200):
+        pick = sel[rng.choice(len(sel), side * side, replace=False)]
+        Pg = P[:, pick[:, 0], pick[:, 1]]                                   # (3, side*side)
+        Rg, ag = R[:, pick[:, 0], pick[:, 1]], a[pick[:, 0], pick[:, 1]]
+        J = np.arange(-40, 41)
+        best = None
+        for i in range(side * side):                                         # camera offsets along ray i
+            oj = (J * 2.0 ** -52)[None, :] * Rg[:, i][:, None]
+            bad = np.zeros(len(J), int)
+            for m in range(side * side):
+                N, T = _numerators(oj, Rg[:, m], ag[m], spheres)
+                bad += (np.argmin(T, axis=0) != np.argmin(N, axis=0)) & np.isfinite(T.min(axis=0))
+            j = int(np.argmax(bad))
+            if best is None or bad[j] > best[0]:
+                best = (int(bad[j]), oj[:, j].copy())
+        if best[0] >= 1:
+            cases.append(dict(pixel_loc=Pg.reshape(3, side, side).copy(), cam_origin=best[1], spheres=spheres.copy(),
+                              disagreeing=best[0]))
+        if len(cases) == ncases:
+            break
+    return cases
+
+
+def gen_tie_cases(mods):
+    """tests/golden/tie_break.npz: the reference's own render() on the scenes of find_tie_cases()."""
+    kernels = mods[0]
+    cases = find_tie_cases()
+    assert cases, "no tie case found"
+    out = dict(n=len(cases))
+    for ci, c in enumerate(cases):
+        side = c["pixel_loc"].shape[1]
+        captured = []
+        orig = kernels.clip_color_vector
+
+        def spy(c3):
+            captured.append((float(c3[0]), float(c3[1]), float(c3[2])))
+            return orig(c3)
+        kernels.clip_color_vector = spy
+        try:
+            result = np.zeros((3, side, side), np.uint8)
+            coords = [(x, y) for x in range(side) for y in range(side)]
+            kernels.render.over(coords)(c["pixel_loc"], result, c["cam_origin"], np.eye(3), c["spheres"],
+                                         np.zeros((3, 0), np.float32), np.zeros((9, 0), np.float32),
+                                         np.float64(1.0), np.float64(0.0), np.float64(0.0), 0, False)
+        finally:
+            kernels.clip_color_vector = orig
+        out[f"pixel_loc_{ci}"] = c["pixel_loc"]
+        out[f"cam_origin_{ci}"] = c["cam_origin"]
+        out[f"spheres_{ci}"] = c["spheres"]
+        out[f"u8_{ci}"] = result
+        out[f"rgb64_{ci}"] = np.array(captured, dtype=np.float64).reshape(side, side, 3).transpose(2, 0, 1)
+        out[f"disagreeing_{ci}"] = c["disagreeing"]
+    path = os.path.join(OUT, "tie_break.npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path)/1024:.0f} KiB, {len(cases)} cases, "
+          f"{[c['disagreeing'] for c in cases]} disagreeing pixels)", flush=True)
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -402,6 +513,8 @@ def main():
         gen_kats(mods)
     if want("host"):
         gen_host_helpers(mods)
+    if want("tie"):
+        gen_tie_cases(mods)
 
     L3 = lig(DEFAULT_LIGHTS)
     P1 = pla([DEFAULT_PLANE])

@@ -5,13 +5,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MI355RT_SO") or os.path.join(HERE, "libmi355rt.so")   # env override: A/B profiling of other builds
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 RT_MAX_DEPTH = 16
 RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 RT_AA_NONE, RT_AA_REFERENCE, RT_AA_STOCHASTIC = 0, 1, 2
 RT_MAX_SPP = 64
-RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB, RT_FLAG_NO_FEEDBACK, RT_FLAG_U8_HWC = 1, 2, 4, 8
+RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB, RT_FLAG_NO_FEEDBACK, RT_FLAG_U8_HWC, RT_FLAG_COUNT_RAYS = 1, 2, 4, 8, 16
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_DEVICE", -4: "RT_ERR_STATE", -5: "RT_ERR_ALLOC"}
 
@@ -24,6 +24,11 @@ class rt_params(C.Structure):
 
 class rt_kernel_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("vgprs", "sgprs", "lds_static", "max_threads", "wave_size", "cu_count", "clock_khz", "reserved")]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("launches", "launches_measuring", "launches_settled", "table_builds",
+                                          "closest_queries", "hits", "shadow_traced", "shadow_skipped")]
 
 
 # name -> (restype, argtypes); must list every function include/mi355rt.h declares.
@@ -44,10 +49,13 @@ PROTOTYPES = {
     "rt_stream_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "rt_stream_destroy": (C.c_int, [_vp, _vp]),
     "rt_stream_sync": (C.c_int, [_vp, _vp]),
+    "rt_stream_forget": (C.c_int, [_vp, _vp]),
     "rt_timer_begin": (C.c_int, [_vp, _vp]),
     "rt_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "rt_get_kernel_info": (C.c_int, [_vp, C.POINTER(rt_kernel_info)]),
     "rt_set_tile_stats": (C.c_int, [_vp, _vp]),
+    "rt_get_stats": (C.c_int, [_vp, C.POINTER(rt_stats)]),
+    "rt_reset_stats": (C.c_int, [_vp]),
     "rt_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rt_free": (C.c_int, [_vp, _vp]),
     "rt_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -46,14 +46,25 @@ struct rt_ctx {
     // the next render, was measured slower: the cross-stream event waits cost more than the 8 us they hide.)
     struct Feedback {
         Buf hist, slot, order;        // cost histogram, per-block (bucket, rank), dispatch order
-        long long key = -1;           // launch geometry `order` was built for (-1: none)
+        struct Key {                  // launch geometry `order` was built for (valid = false: none)
+            bool valid = false;
+            int x0 = 0, x1 = 0, h = 0, aa = 0, depth = 0, spp = 0, wpw = 0;
+            bool operator==(const Key &o) const
+            {
+                return valid && o.valid && x0 == o.x0 && x1 == o.x1 && h == o.h && aa == o.aa && depth == o.depth &&
+                       spp == o.spp && wpw == o.wpw;
+            }
+        } key;
         hipStream_t stream = nullptr; // stream it was built on
         unsigned long long epoch = 0; // ctx->epoch the costs were measured under
         int builds = 0;               // consecutive builds under that key and epoch
         hipEvent_t done = nullptr;    // recorded behind every order kernel
+        hipEvent_t handover = nullptr; // recorded on the owner's stream when another stream takes the buffers over
         std::vector<std::pair<hipStream_t, hipEvent_t>> readers;   // other streams dispatching in the settled order
         std::vector<hipEvent_t> spare;
     } fb;
+    rt_stats stats = {};              // host-side launch counters (the ray counters live in `counts`)
+    Buf counts;                       // 4 x uint64 on the device: ray counters of RT_FLAG_COUNT_RAYS launches
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
     unsigned long long scene_epoch = 1;   // bumped by rt_set_scene only
     // The float32 cull tables (rt::tables_kernel) of the last few (scene, camera position, floor) combinations.
@@ -124,8 +135,10 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     return RT_OK;
 }
 
-const void *kernel_variant(bool aa, bool park, int wpw)
+const void *kernel_variant(bool aa, bool park, int wpw, bool count = false)
 {
+    if (count)      // rt_get_stats: the register variant with workgroups of 4 carries the ray counters
+        return aa ? (const void *)rt::render_kernel<true, false, 4, true> : (const void *)rt::render_kernel<false, false, 4, true>;
     if (wpw == 2)
         return aa ? (park ? (const void *)rt::render_kernel<true, true, 2> : (const void *)rt::render_kernel<true, false, 2>)
                   : (park ? (const void *)rt::render_kernel<false, true, 2> : (const void *)rt::render_kernel<false, false, 2>);
@@ -178,6 +191,7 @@ int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const 
     if (rc != RT_OK) return rc;
     if (!t.built) RT_HIP(ctx, hipEventCreateWithFlags(&t.built, hipEventDisableTiming));
     hipLaunchKernelGGL(rt::tables_kernel, dim3(1), dim3(rt::TABLE_THREADS), 0, stream, k, (float *)t.buf.p);
+    ctx->stats.table_builds++;
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(t.built, stream));
     hipEvent_t ev = nullptr;
@@ -234,26 +248,37 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 24 wavefronts per CU still
     // fit their workgroups' LDS images; otherwise the register variant (its occupancy is then LDS-bound anyway).
     const bool aa = k.aa != 0;
+    const bool count = (p->flags & RT_FLAG_COUNT_RAYS) != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    const int wpw = image <= 4608 ? 2 : 4;      // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
+    const int wpw = (image <= 4608 && !count) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
-    const bool park = lds_park * (24 / wpw) <= 160 * 1024;
+    const bool park = !count && lds_park * (24 / wpw) <= 160 * 1024;
     const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt);
-    const void *fn = kernel_variant(aa, park, wpw);
+    const void *fn = kernel_variant(aa, park, wpw, count);
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 2; ++v)
+            RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
+    }
+    if (count) {
+        if (!ctx->counts.p) {
+            int rc0 = ensure(ctx, ctx->counts, 4 * sizeof(unsigned long long));
+            if (rc0 != RT_OK) return rc0;
+            RT_HIP(ctx, hipMemsetAsync(ctx->counts.p, 0, 4 * sizeof(unsigned long long), stream));
+        }
+        k.ray_counts = (unsigned long long *)ctx->counts.p;
     }
     const unsigned grid = (unsigned)((k.ntiles + wpw - 1) / wpw);
     // Scheduler feedback (longest-first dispatch): a launch files its tile blocks by cost and dispatches in the
     // order built from the previous measured launch of the same range, depth and AA mode.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
-    const long long key = ((long long)x0 << 42) ^ ((long long)x1 << 21) ^ (long long)ctx->h ^ ((long long)k.aa << 62)
-                          ^ ((long long)k.depth << 56) ^ ((long long)(k.aa == RT_AA_STOCHASTIC ? k.spp : 0) << 48)
-                          ^ ((long long)wpw << 18);
+    rt_ctx::Feedback::Key key;
+    key.valid = true; key.x0 = x0; key.x1 = x1; key.h = ctx->h; key.aa = k.aa; key.depth = k.depth;
+    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw;
     rt_ctx::Feedback &f = ctx->fb;
     // Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile
     // order, once from longest-first order): the costs are the same again, so the launch neither measures nor
@@ -279,10 +304,17 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
             }
         }
     } else if (feedback) {
-        measure = f.key == -1 || stream == f.stream || hipEventQuery(f.done) == hipSuccess;
+        measure = !f.key.valid || stream == f.stream || hipEventQuery(f.done) == hipSuccess;
         (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
     }
     if (measure) {
+        // Taking the buffers over from another stream: hipEventQuery(f.done) only proves that the owner's last
+        // ORDER KERNEL has finished.  Settled launches the owner queued after it still read `order` (the owner is
+        // not in f.readers), so this stream waits for everything the owner has queued so far.
+        if (f.key.valid && f.stream != stream) {
+            RT_HIP(ctx, hipEventRecord(f.handover, f.stream));
+            RT_HIP(ctx, hipStreamWaitEvent(stream, f.handover, 0));
+        }
         for (auto &r : f.readers) {                            // settled launches elsewhere may still read `order`
             if (r.first != stream) {
                 RT_HIP(ctx, hipEventRecord(r.second, r.first));
@@ -296,7 +328,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
             if (rc0 != RT_OK) return rc0;
             RT_HIP(ctx, hipMemsetAsync(f.hist.p, 0, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned), stream));
         }
-        if (f.slot.cap < (size_t)grid * sizeof(unsigned) || f.order.cap < (size_t)grid * sizeof(unsigned)) f.key = -1;
+        if (f.slot.cap < (size_t)grid * sizeof(unsigned) || f.order.cap < (size_t)grid * sizeof(unsigned)) f.key.valid = false;
         int rc = ensure(ctx, f.slot, (size_t)grid * sizeof(unsigned));
         if (rc == RT_OK) rc = ensure(ctx, f.order, (size_t)grid * sizeof(unsigned));
         if (rc != RT_OK) return rc;
@@ -306,6 +338,9 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     }
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(wgt), args, lds, stream));
+    ctx->stats.launches++;
+    if (settled) ctx->stats.launches_settled++;
+    if (measure) ctx->stats.launches_measuring++;
     if (measure) {
         hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
                            (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid);
@@ -350,7 +385,8 @@ int rt_create(rt_ctx **out, int device)
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-        (s = hipEventCreateWithFlags(&ctx->fb.done, hipEventDisableTiming)) != hipSuccess) {
+        (s = hipEventCreateWithFlags(&ctx->fb.done, hipEventDisableTiming)) != hipSuccess ||
+        (s = hipEventCreateWithFlags(&ctx->fb.handover, hipEventDisableTiming)) != hipSuccess) {
         std::string m = std::string("context setup: ") + hipGetErrorString(s);
         delete ctx;
         return fail(nullptr, RT_ERR_HIP, m);
@@ -364,7 +400,7 @@ int rt_destroy(rt_ctx *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->fb.hist, &ctx->fb.slot, &ctx->fb.order})
+    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->fb.hist, &ctx->fb.slot, &ctx->fb.order, &ctx->counts})
         if (b->p) (void)hipFree(b->p);
     for (auto &t : ctx->tables) {
         if (t.buf.p) (void)hipFree(t.buf.p);
@@ -375,6 +411,7 @@ int rt_destroy(rt_ctx *ctx)
     for (auto &r : ctx->fb.readers) (void)hipEventDestroy(r.second);
     for (hipEvent_t e : ctx->fb.spare) (void)hipEventDestroy(e);
     if (ctx->fb.done) (void)hipEventDestroy(ctx->fb.done);
+    if (ctx->fb.handover) (void)hipEventDestroy(ctx->fb.handover);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -500,6 +537,10 @@ int rt_set_camera(rt_ctx *ctx, const double origin[3], const double rotation[9])
 {
     if (!ctx) return RT_ERR_BAD_ARG;
     if (!origin || !rotation) return fail(ctx, RT_ERR_BAD_ARG, "NULL camera array");
+    // the same camera again (the reference's driver passes it with every launch, main.py:41-47) changes nothing a
+    // tile's cost depends on: the measured dispatch order and the cull tables stay valid
+    if (ctx->have_cam && std::memcmp(ctx->cam_o, origin, sizeof ctx->cam_o) == 0 &&
+        std::memcmp(ctx->cam_R, rotation, sizeof ctx->cam_R) == 0) return RT_OK;
     std::memcpy(ctx->cam_o, origin, sizeof ctx->cam_o);
     std::memcpy(ctx->cam_R, rotation, sizeof ctx->cam_R);
     ctx->have_cam = true;
@@ -511,6 +552,11 @@ int rt_set_raygen(rt_ctx *ctx, int w, int h, double px, double y0, double dy, do
 {
     if (!ctx) return RT_ERR_BAD_ARG;
     if (w < 1 || h < 1 || (long long)w * h > (1ll << 31)) return fail(ctx, RT_ERR_BAD_ARG, "frame size out of range");
+    {
+        const double now[5] = {px, y0, dy, z0, dz}, was[5] = {ctx->px, ctx->y0, ctx->dy, ctx->z0, ctx->dz};
+        if (ctx->have_grid && !ctx->explicit_grid && ctx->w == w && ctx->h == h && std::memcmp(now, was, sizeof now) == 0)
+            return RT_OK;                                       // unchanged: keep the measured dispatch order
+    }
     ctx->w = w; ctx->h = h; ctx->px = px; ctx->y0 = y0; ctx->dy = dy; ctx->z0 = z0; ctx->dz = dz;
     ctx->explicit_grid = false;
     ctx->have_grid = true;
@@ -630,26 +676,43 @@ int rt_stream_create(rt_ctx *ctx, void **stream)
     return RT_OK;
 }
 
+// The context remembers streams that launched on it (owner / readers of the dispatch order, readers of the cull
+// tables) so that it can fence them later: drop every reference to `stream` once its queued work is complete.
+static int forget_stream(rt_ctx *ctx, hipStream_t stream)
+{
+    RT_HIP(ctx, hipStreamSynchronize(stream));
+    rt_ctx::Feedback &f = ctx->fb;
+    for (size_t i = 0; i < f.readers.size();) {
+        if (f.readers[i].first == stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }
+        else ++i;
+    }
+    if (f.stream == stream) f.stream = ctx->stream;             // its work is complete: anyone may take over
+    for (auto &t : ctx->tables)
+        for (size_t i = 0; i < t.readers.size();) {
+            if (t.readers[i].first == stream) { ctx->spare_events.push_back(t.readers[i].second); t.readers.erase(t.readers.begin() + (long)i); }
+            else ++i;
+        }
+    return RT_OK;
+}
+
 int rt_stream_destroy(rt_ctx *ctx, void *stream)
 {
     if (!ctx) return RT_ERR_BAD_ARG;
     if (!stream) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-    // the scheduler feedback may remember this stream as owner or reader: forget it
-    rt_ctx::Feedback &f = ctx->fb;
-    for (size_t i = 0; i < f.readers.size();) {
-        if (f.readers[i].first == (hipStream_t)stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }
-        else ++i;
-    }
-    if (f.stream == (hipStream_t)stream) f.stream = ctx->stream;   // its work is complete: anyone may take over
-    for (auto &t : ctx->tables)
-        for (size_t i = 0; i < t.readers.size();) {
-            if (t.readers[i].first == (hipStream_t)stream) { ctx->spare_events.push_back(t.readers[i].second); t.readers.erase(t.readers.begin() + (long)i); }
-            else ++i;
-        }
+    int rc = forget_stream(ctx, (hipStream_t)stream);
+    if (rc != RT_OK) return rc;
     RT_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
     return RT_OK;
+}
+
+int rt_stream_forget(rt_ctx *ctx, void *stream)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!stream) return RT_OK;
+    if ((hipStream_t)stream == ctx->stream) return fail(ctx, RT_ERR_BAD_ARG, "rt_stream_forget: the context's own stream");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return forget_stream(ctx, (hipStream_t)stream);
 }
 
 int rt_stream_sync(rt_ctx *ctx, void *stream)
@@ -683,6 +746,33 @@ int rt_set_tile_stats(rt_ctx *ctx, void *d_cycles)
 {
     if (!ctx) return RT_ERR_BAD_ARG;
     ctx->tile_stats = (unsigned *)d_cycles;
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!out) return fail(ctx, RT_ERR_BAD_ARG, "stats is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long c[4] = {0, 0, 0, 0};
+    if (ctx->counts.p) {                                        // counting launches may be in flight on any stream
+        RT_HIP(ctx, hipDeviceSynchronize());
+        RT_HIP(ctx, hipMemcpy(c, ctx->counts.p, sizeof c, hipMemcpyDeviceToHost));
+    }
+    *out = ctx->stats;
+    out->closest_queries = c[0]; out->shadow_traced = c[1]; out->shadow_skipped = c[2]; out->hits = c[3];
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->counts.p) {
+        RT_HIP(ctx, hipDeviceSynchronize());
+        RT_HIP(ctx, hipMemset(ctx->counts.p, 0, 4 * sizeof(unsigned long long)));
+    }
+    ctx->stats = rt_stats{};
     return RT_OK;
 }
 

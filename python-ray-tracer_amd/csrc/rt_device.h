@@ -74,6 +74,7 @@ struct KParams {
     unsigned *slot;            // per tile block: (bucket << 20) | arrival rank within the bucket
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from the previous launch's costs
     const float *ftab;         // the float32 cull tables of this scene / camera / depth, built once by tables_kernel
+    unsigned long long *ray_counts;   // counting instantiation only (RT_FLAG_COUNT_RAYS): {closest, shadow issued, shadow skipped, hits}
     long long plane_stride;    // elements between colour planes of the output
     int w, h, x0, x1;
     int S, P, L, depth;
@@ -520,9 +521,25 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
             const double q = __builtin_sqrt(D);
             double n = -s - q;                                // :28
             if (!(n > 0.0)) n = -s + q;                       // :33
-            // the smallest wins and, on an exact tie, the lower caller's index (trace.py:26: strict <, ascending
-            // order) — slots are visited in slot order, which for clustered scenes is a permutation
-            if (n > 0.0 && (n < bestn || (n == bestn && g[7] < borig))) { bestn = n; bidx = k; borig = g[7]; }
+            // The reference compares the rounded quotients t = n/a with a strict `best > t`, in ascending caller
+            // index (trace.py:26): the smallest t wins and, among equal t, the lowest index.  Division by the
+            // common a > 0 and rounding are monotone, so numerators order the quotients — except that two
+            // numerators within a couple of ulp of each other may round to the SAME quotient, where the index
+            // decides.  Numerators further apart than a relative 2^-50 have different quotients in the same
+            // order (the gap is four ulp); for closer ones (equal included) both quotients are formed and the
+            // reference's rule is applied literally.  Wave-uniform branch, practically never taken.
+            // Slots are visited in slot order, which for clustered scenes is a permutation: g[7] is the caller's index.
+            if (n > 0.0) {
+                bool take = n < bestn;
+                const bool close = __builtin_fabs(n - bestn) < bestn * 0x1p-50;   // false while bestn = +inf
+                if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+                    if (close) {
+                        const double tq = n / a, tb = bestn / a;                  // :31 / :36
+                        take = tq < tb || (tq == tb && g[7] < borig);
+                    }
+                }
+                if (take) { bestn = n; bidx = k; borig = g[7]; }
+            }
         }
       }
     }
@@ -620,17 +637,33 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
     return occ;
 }
 
+// Per-lane ray counters of the counting instantiation (rt_get_stats); empty, and every call a no-op, otherwise.
+template <bool COUNT> struct RayCount {
+    __device__ __forceinline__ void closest(bool) {}
+    __device__ __forceinline__ void hit(bool) {}
+    __device__ __forceinline__ void shadow(bool, bool) {}
+};
+template <> struct RayCount<true> {
+    unsigned n_closest = 0, n_issued = 0, n_skipped = 0, n_hit = 0;
+    __device__ __forceinline__ void closest(bool alive) { n_closest += alive ? 1u : 0u; }      // trace.py:53
+    __device__ __forceinline__ void hit(bool alive) { n_hit += alive ? 1u : 0u; }
+    // trace.py:92 issues a shadow query per light and hit; the kernel traces it only where its answer is used (k > 0)
+    __device__ __forceinline__ void shadow(bool alive, bool traced) { n_issued += (alive && traced) ? 1u : 0u; n_skipped += (alive && !traced) ? 1u : 0u; }
+};
+
 // trace.py:44-112.  On entry `alive` lanes carry a ray (o,d); on exit `alive` is false for lanes
 // that missed (the reference's 404 sentinels), rgb is this bounce's colour, (o,d) the next ray.
-template <bool PARK, int WGT>
+template <bool PARK, int WGT, bool COUNT>
 __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
-                                             V3 &o, V3 &d, V3 &rgb)
+                                             V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt)
 {
     const int S = p.S, P = p.P, L = p.L;
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
+    cnt.closest(alive);
     if (alive) closest_hit(lds, p, o, d, anchor, t, idx, type);               // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
+    cnt.hit(alive);
     if (alive) {
         V3 Pt{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                   // :60 (1.0*o is exact)
         // PARK: the object's colour is re-read from its LDS record where it is used (volatile: at the point of
@@ -663,6 +696,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             const double k = p.lamb * dot3(Ld, N);                            // :99
             // :92-102 — the shadow query's answer is only used when k > 0; it has no other effect,
             // so lanes with k <= 0 (light behind the surface) do not ask.
+            cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
                 const bool occluded = any_hit(lds, p, Pt, Ld, 1 + m, self);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
@@ -679,15 +713,15 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 }
 
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
-template <bool PARK, int WGT>
-__device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d)
+template <bool PARK, int WGT, bool COUNT>
+__device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
     Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
     for (int b = 0; b <= p.depth; ++b) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;                                   // wave-uniform exit
         V3 rgb;
-        trace_bounce<PARK, WGT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb);
+        trace_bounce<PARK, WGT, COUNT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
             const double wgt = p.refl_pow[b - 1];
@@ -815,7 +849,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
-template <bool AA, bool PARK, int WPW>
+template <bool AA, bool PARK, int WPW, bool COUNT = false>
 #ifndef RT_W_PARK
 #define RT_W_PARK 7
 #endif
@@ -869,9 +903,10 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
     if constexpr (PARK) *offp = inb ? (x - p.x0) * p.h + y : -1;              // w*h <= 2^31 (checked by the host)
 
     const V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]};                           // kernels.py:16
+    RayCount<COUNT> cnt;
     double R, G, B;
     if constexpr (!AA) {
-        const V3 c = sample<PARK, WG_THREADS>(lds, p, inb, o, primary_dir(p, pixel_P(p, xc, yc)));   // kernels.py:19-26
+        const V3 c = sample<PARK, WG_THREADS, COUNT>(lds, p, inb, o, primary_dir(p, pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
         R = c.x; G = c.y; B = c.z;
     } else {
         // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
@@ -899,7 +934,7 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
                 const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
                 Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
             }
-            const V3 s = sample<PARK, WG_THREADS>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt));   // :26 / :56
+            const V3 s = sample<PARK, WG_THREADS, COUNT>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt), cnt);   // :26 / :56
             if (tap == 0) taps.set(s);
             else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.y, a.z + s.z}); }
             else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.z, a.z + s.y}); }   // :58-60 (G += B_s; B += G_s)
@@ -929,6 +964,15 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
             p.out_f32[off] = (float)R;
             p.out_f32[p.plane_stride + off] = (float)G;
             p.out_f32[2 * p.plane_stride + off] = (float)B;
+        }
+    }
+    if constexpr (COUNT) {                                                    // rt_get_stats: one atomic per wave and counter
+        unsigned v[4] = {cnt.n_closest, cnt.n_issued, cnt.n_skipped, cnt.n_hit};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v[c] += __shfl_down(v[c], d);
+            if ((threadIdx.x & 63) == 0 && p.ray_counts) atomicAdd(&p.ray_counts[c], (unsigned long long)v[c]);
         }
     }
     if ((p.tile_cycles || p.hist) && (threadIdx.x & 63) == 0) {               // timing only; never feeds a pixel

@@ -6,11 +6,14 @@ A DeviceNDArray keeps the host values it was created from (scene arrays and came
 consumed by the C ABI as host pointers) and, once a launch has written to it, a device buffer that
 `copy_to_host()` reads back after synchronising — the launch itself is asynchronous, as in numba.
 """
+import itertools
+
 import numpy as np
 
 from .renderer import Renderer
 
 _default = None
+_serials = itertools.count(1)
 
 
 def current_renderer(device=0):
@@ -35,6 +38,7 @@ class DeviceNDArray:
         self._renderer = None
         self._dirty = False          # device buffer newer than _host
         self.version = 0             # bumped whenever the contents change (launch caches key on it)
+        self.serial = next(_serials) # process-unique identity (id() values are reused after garbage collection)
 
     shape = property(lambda self: self._host.shape)
     dtype = property(lambda self: self._host.dtype)

@@ -17,6 +17,11 @@ from .. import cuda as _cuda
 from .. import _lib as L
 
 
+def _key(a):
+    """(serial, version) of a cuda.to_device handle; None for anything else (plain arrays are always re-sent)."""
+    return (a.serial, a.version) if isinstance(a, _cuda.DeviceNDArray) else None
+
+
 def _host(a):
     return a._host if isinstance(a, _cuda.DeviceNDArray) else np.asarray(a)
 
@@ -36,14 +41,21 @@ class _Launch:
                  amb, lamb, refl, refl_depth, aliasing):
         r = _cuda.current_renderer()
         k = self.kernel
-        # -- inputs: re-sent only when the handles (or their contents' version) changed ----------
-        scene_key = tuple((id(a), getattr(a, "version", None)) for a in (spheres, lights, planes))
-        if any(v is None for _, v in scene_key) or scene_key != k._scene_key:
+        # -- inputs: re-sent only when the handles (or their contents' version) changed.  A handle is identified by
+        # its process-unique serial, never by id(): CPython reuses the addresses of freed objects, so a scene built
+        # per frame in a helper (`render[g,b](..., *build_scene(i), ...)`) would otherwise alias the previous one.
+        # The cache also records the context's own generation counters, so a context that was re-created or fed
+        # through the Renderer API in between is never assumed to hold what this facade sent last.
+        scene_key = tuple(_key(a) for a in (spheres, lights, planes)) + (k.scene_flags,)
+        if any(e is None for e in scene_key) or (scene_key, r.serial, r.generation["scene"]) != k._scene_key:
             r.set_scene(_host(spheres), _host(lights), _host(planes), k.scene_flags)
-            k._scene_key = scene_key
-        r.set_camera(_host(camera_origin), _host(camera_rotation))
-        grid_key = (id(pixel_loc), getattr(pixel_loc, "version", None))
-        if grid_key[1] is None or grid_key != k._grid_key:
+            k._scene_key = (scene_key, r.serial, r.generation["scene"])
+        cam_key = (_key(camera_origin), _key(camera_rotation))
+        if None in cam_key or (cam_key, r.serial, r.generation["camera"]) != k._cam_key:   # (the library itself ignores an unchanged camera)
+            r.set_camera(_host(camera_origin), _host(camera_rotation))
+            k._cam_key = (cam_key, r.serial, r.generation["camera"])
+        grid_key = _key(pixel_loc)
+        if grid_key is None or (grid_key, r.serial, r.generation["grid"]) != k._grid_key:
             rg = getattr(pixel_loc, "raygen", None)
             hp = _host(pixel_loc)
             if hp.ndim != 3 or hp.shape[0] != 3:
@@ -52,7 +64,7 @@ class _Launch:
                 r.set_raygen(hp.shape[1], hp.shape[2], *rg)
             else:
                 r.set_pixel_loc(hp)
-            k._grid_key = grid_key
+            k._grid_key = (grid_key, r.serial, r.generation["grid"])
         w, h = r.w, r.h
         if tuple(result.shape) != (3, w, h) or result.dtype != np.uint8:
             raise ValueError(f"result must be uint8 with shape (3, {w}, {h}), got {result.dtype} {tuple(result.shape)}")
@@ -88,6 +100,7 @@ class RenderKernel:
         self.scene_flags = 0     # RT_FLAG_TYPED_BIAS to evaluate the plane BIAS*N product in float64
         self.render_flags = 0    # RT_FLAG_U8_RGB for true (R,G,B) byte order
         self._scene_key = None
+        self._cam_key = None
         self._grid_key = None
 
     def __getitem__(self, cfg):

@@ -1,6 +1,7 @@
 """Renderer — thin object wrapper over the C ABI (include/mi355rt.h).  One Renderer = one rt_ctx
 = one GPU.  All pixel work happens in libmi355rt.so; this class only marshals arrays."""
 import ctypes as C
+import itertools
 
 import numpy as np
 
@@ -31,8 +32,12 @@ def _f32(a, rows, name):
     return a
 
 
+_serials = itertools.count(1)
+
+
 class Renderer:
     def __init__(self, device=0, lib=None):
+        self.serial = next(_serials)     # process-unique (id() values are reused after garbage collection)
         self._lib = lib if lib is not None else L.load()
         self._ctx = C.c_void_p()
         st = self._lib.rt_create(C.byref(self._ctx), int(device))
@@ -40,6 +45,7 @@ class Renderer:
             raise RenderError(st, self._lib.rt_last_error(None).decode())
         self.device = int(device)
         self.w = self.h = None
+        self.generation = {"scene": 0, "camera": 0, "grid": 0}   # bumped by every set_*: caches above this class key on it
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, st):
@@ -71,6 +77,7 @@ class Renderer:
         self._check(self._lib.rt_set_scene(self._ctx, s.ctypes.data_as(fp), s.shape[1], l.ctypes.data_as(fp), l.shape[1],
                                            p.ctypes.data_as(fp), p.shape[1], int(flags)))
         self.counts = (s.shape[1], l.shape[1], p.shape[1])
+        self.generation["scene"] += 1
 
     def set_camera(self, origin, rotation):
         """camera_origin (3,), camera_rotation (3,3); forced to float64 (an all-int position list
@@ -79,10 +86,12 @@ class Renderer:
         r = np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
         dp = C.POINTER(C.c_double)
         self._check(self._lib.rt_set_camera(self._ctx, o.ctypes.data_as(dp), r.ctypes.data_as(dp)))
+        self.generation["camera"] += 1
 
     def set_raygen(self, w, h, px, y0, dy, z0, dz):
         self._check(self._lib.rt_set_raygen(self._ctx, int(w), int(h), float(px), float(y0), float(dy), float(z0), float(dz)))
         self.w, self.h = int(w), int(h)
+        self.generation["grid"] += 1
 
     def set_pixel_loc(self, pixel_loc):
         a = np.ascontiguousarray(pixel_loc, dtype=np.float64)
@@ -90,6 +99,7 @@ class Renderer:
             raise ValueError(f"pixel_loc must have shape (3, w, h), got {a.shape}")
         self._check(self._lib.rt_set_pixel_loc(self._ctx, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[1], a.shape[2]))
         self.w, self.h = a.shape[1], a.shape[2]
+        self.generation["grid"] += 1
 
     def set_grid(self, pixel_loc):
         """Use the closed form when the array carries one (scene.camera.PixelGrid), else upload it."""
@@ -151,6 +161,12 @@ class Renderer:
         if stream and self._ctx.value:
             self._check(self._lib.rt_stream_destroy(self._ctx, C.c_void_p(stream)))
 
+    def stream_forget(self, stream):
+        """Before the owner of a foreign stream (e.g. a torch.cuda.Stream) destroys it: wait for it and drop the
+        context's reference to its handle."""
+        if stream and self._ctx.value:
+            self._check(self._lib.rt_stream_forget(self._ctx, C.c_void_p(stream)))
+
     def timer_begin(self, stream=None):
         self._check(self._lib.rt_timer_begin(self._ctx, C.c_void_p(stream) if stream else None))
 
@@ -162,6 +178,15 @@ class Renderer:
     def set_tile_stats(self, dptr):
         """Device buffer (uint32 per 8x8 tile) that later launches fill with per-tile wave cycles; None = off."""
         self._check(self._lib.rt_set_tile_stats(self._ctx, C.c_void_p(dptr) if dptr else None))
+
+    def stats(self):
+        """rt_stats as a dict: launch counters, and the ray counters of RT_FLAG_COUNT_RAYS launches."""
+        st = L.rt_stats()
+        self._check(self._lib.rt_get_stats(self._ctx, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
+    def reset_stats(self):
+        self._check(self._lib.rt_reset_stats(self._ctx))
 
     def kernel_info(self):
         info = L.rt_kernel_info()

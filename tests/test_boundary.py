@@ -92,3 +92,64 @@ def test_facade_argument_validation():
         render[(1, 1)]
     with pytest.raises(ValueError):
         render[(1, 1), (0, 8)]
+
+
+class _FakeRenderer:
+    """Records what the facade sends (no GPU): stands in for python_ray_tracer_amd.Renderer."""
+
+    def __init__(self):
+        from python_ray_tracer_amd.renderer import Renderer
+        self.serial = -1
+        self.generation = {"scene": 0, "camera": 0, "grid": 0}
+        self.scenes, self.cameras, self.grids = [], [], []
+        self.w = self.h = None
+        self.params = Renderer.params
+
+    def set_scene(self, s, l, p, flags=0):
+        self.scenes.append(float(s[0, 0])); self.generation["scene"] += 1
+
+    def set_camera(self, o, r):
+        self.cameras.append(float(o[0])); self.generation["camera"] += 1
+
+    def set_raygen(self, w, h, *a):
+        self.w, self.h = w, h; self.grids.append(("closed", w, h)); self.generation["grid"] += 1
+
+    def set_pixel_loc(self, a):
+        self.w, self.h = a.shape[1], a.shape[2]; self.grids.append(("explicit",) + a.shape[1:]); self.generation["grid"] += 1
+
+    def render(self, *a, x0=0, x1=None, **k):
+        import numpy as np
+        return np.zeros((3, x1 - x0, self.h), np.uint8), None
+
+
+def test_facade_never_aliases_fresh_handles(monkeypatch):
+    """a scene built per frame through fresh cuda.to_device handles (whose id() CPython reuses) must be
+    re-sent every frame; the same handles again must not be; a changed camera handle must be."""
+    import numpy as np
+    from python_ray_tracer_amd import cuda
+    from python_ray_tracer_amd.ray_tracing.kernels import RenderKernel
+    fake = _FakeRenderer()
+    monkeypatch.setattr(cuda, "_default", fake)
+    render = RenderKernel()
+    w = h = 8
+    grid = cuda.to_device(np.zeros((3, w, h)))
+    cam_o, cam_R = cuda.to_device(np.zeros(3)), cuda.to_device(np.eye(3))
+
+    def build_scene(i):
+        sp = np.zeros((7, 1), np.float32); sp[0, 0] = i
+        return cuda.to_device(sp), cuda.to_device(np.zeros((3, 1), np.float32)), cuda.to_device(np.zeros((9, 1), np.float32))
+
+    for i in range(6):                                   # handles die at the end of every iteration
+        render[(1, 1), (8, 8)](grid, np.zeros((3, w, h), np.uint8), cam_o, cam_R, *build_scene(i), 0.0, 0.6, 0.3, 1, False)
+    assert fake.scenes == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    assert len(fake.cameras) == 1 and len(fake.grids) == 1
+    keep = build_scene(9)
+    for _ in range(3):
+        render[(1, 1), (8, 8)](grid, np.zeros((3, w, h), np.uint8), cam_o, cam_R, *keep, 0.0, 0.6, 0.3, 1, False)
+    assert fake.scenes[6:] == [9.0]                      # sent once, then cached
+    cam2 = cuda.to_device(np.ones(3))
+    render[(1, 1), (8, 8)](grid, np.zeros((3, w, h), np.uint8), cam2, cam_R, *keep, 0.0, 0.6, 0.3, 1, False)
+    assert fake.cameras == [0.0, 1.0]
+    fake.set_scene(np.full((7, 1), 7.0, np.float32), None, None)   # someone else talks to the same context
+    render[(1, 1), (8, 8)](grid, np.zeros((3, w, h), np.uint8), cam2, cam_R, *keep, 0.0, 0.6, 0.3, 1, False)
+    assert fake.scenes[-1] == 9.0 and len(fake.scenes) == 9          # the facade re-sends its scene

@@ -81,6 +81,21 @@ def test_c2_headline_frame_full(renderer, oracle):
     assert err <= TOL
 
 
+def test_closest_hit_tie_rule(renderer):
+    """Known-answer test for the reference's tie rule (trace.py:26): in these scenes ~60 of 64 pixels see two spheres
+    whose numerators differ while their distances t = n/a round to the same double; the reference keeps the lower
+    index.  Golden = the reference's own render() (tests/golden/tie_break.npz)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tie_break.npz"))
+    for ci in range(int(g["n"])):
+        pl = g[f"pixel_loc_{ci}"]
+        renderer.set_scene(g[f"spheres_{ci}"], np.zeros((3, 0), np.float32), np.zeros((9, 0), np.float32))
+        renderer.set_camera(g[f"cam_origin_{ci}"], np.eye(3))
+        renderer.set_pixel_loc(pl)
+        u8, f32 = renderer.render(1.0, 0.0, 0.0, 0, 0, u8=True, f32=True)
+        assert np.array_equal(u8, g[f"u8_{ci}"]), f"case {ci}: {(u8 != g[f'u8_{ci}']).any(axis=0).sum()} px differ"
+        assert np.array_equal(f32, g[f"rgb64_{ci}"].astype(np.float32))
+
+
 def test_explicit_pixel_loc_equals_raygen(renderer):
     g = load_frame("odd_37x29")
     _setup(renderer, g, explicit_grid=False)
@@ -270,6 +285,12 @@ def test_frames_pipelined_over_streams(renderer):
         for i in range(n):
             renderer.render_device(p, 0, w, bufs[i % 3], None, w * h, stream=streams[i % 3])
 
+    def remeasure():
+        # an rt_set_* call that changes something starts measuring again (the same camera again does not, by
+        # design: the reference's driver passes it with every launch)
+        renderer.set_camera(np.asarray(g["cam_origin"]) + 1.0, g["cam_rot"])
+        renderer.set_camera(g["cam_origin"], g["cam_rot"])
+
     def check():
         for s in streams:
             renderer.sync(s)
@@ -282,10 +303,10 @@ def test_frames_pipelined_over_streams(renderer):
         for b in bufs:
             renderer.h2d(b, zero)
         burst(12)
-        renderer.set_camera(g["cam_origin"], g["cam_rot"])       # same camera, but the library must measure again
+        remeasure()
         burst(9)
         check()
-        renderer.set_camera(g["cam_origin"], g["cam_rot"])
+        remeasure()
         burst(3)                                                  # measuring phase only: the other streams render in plain order
         check()
         burst(2)
@@ -298,6 +319,93 @@ def test_frames_pipelined_over_streams(renderer):
             renderer.stream_destroy(s)
         for b in bufs:
             renderer.free(b)
+
+
+def test_feedback_takeover_by_another_stream(renderer):
+    """the stream that owns the scheduler-feedback buffers has settled frames queued (they read the
+    dispatch order) when, after an rt_set_* call, the first launch goes to ANOTHER stream, which takes the buffers
+    over and rebuilds the order.  It must wait for the owner's queued frames; every frame must be the reference."""
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+    s0, s1 = renderer.stream_create(), renderer.stream_create()
+    nb = 24
+    bufs = [renderer.malloc(3 * w * h) for _ in range(nb)]
+    zero = np.zeros((3, w, h), np.uint8)
+    try:
+        for rep in range(3):
+            for b in bufs:
+                renderer.h2d(b, zero)
+            for i in range(4):                                    # s0 measures twice and settles
+                renderer.render_device(p, 0, w, bufs[i], None, w * h, stream=s0)
+            renderer.sync(s0)                                     # the order kernel is done: a takeover is allowed
+            for i in range(4, 16):                                # settled frames queued on the owner, not waited for
+                renderer.render_device(p, 0, w, bufs[i], None, w * h, stream=s0)
+            renderer.set_camera(np.asarray(g["cam_origin"]) + 1.0, g["cam_rot"])
+            renderer.set_camera(g["cam_origin"], g["cam_rot"])    # epoch bumped: the next launch measures
+            for i in range(16, nb):                               # ... on the other stream: takes over, rebuilds the order
+                renderer.render_device(p, 0, w, bufs[i], None, w * h, stream=s1)
+            renderer.sync(s0); renderer.sync(s1)
+            for i, b in enumerate(bufs):
+                got = np.empty((3, w, h), np.uint8)
+                renderer.d2h(got, b)
+                assert np.array_equal(got, g["frame_u8"]), f"rep {rep} frame {i}: {(got != g['frame_u8']).any(axis=0).sum()} px differ"
+            s0, s1 = s1, s0
+    finally:
+        renderer.stream_destroy(s0); renderer.stream_destroy(s1)
+        for b in bufs:
+            renderer.free(b)
+
+
+def test_repeated_facade_launches_settle(renderer):
+    """the reference's call shape passes the camera with every launch (main.py:41-47); the same
+    camera again must not restart the dispatch-order measurement.  rt_get_stats counts settled launches."""
+    from python_ray_tracer_amd import cuda
+    from python_ray_tracer_amd.ray_tracing import render
+    from python_ray_tracer_amd.scene import Scene, Camera
+    g = load_frame("default_128_d3")
+    w = h = 128
+    sp, li, pl = (cuda.to_device(a) for a in Scene.default_scene().generate_scene())
+    camera = Camera(resolution=(w, h), position=[-2, 0, 2.0], euler=[0, -30, 0])
+    co, cr = cuda.to_device(camera.position), cuda.to_device(camera.rotation)
+    grid = cuda.to_device(camera.generate_pixel_locations())
+    result = cuda.to_device(np.zeros((3, w, h), dtype=np.uint8))
+    r = cuda.current_renderer()
+    before = r.stats()
+    for _ in range(6):
+        render[(8, 8), (16, 16)](grid, result, co, cr, sp, li, pl, 0.0, 0.6, 0.3, 3, False)
+    assert np.array_equal(result.copy_to_host(), g["frame_u8"])
+    after = r.stats()
+    assert after["launches"] - before["launches"] == 6
+    assert after["launches_settled"] - before["launches_settled"] >= 3      # launches 3.. dispatch in the settled order
+    # plain ndarrays for the camera every time (always re-sent): still settled, the library compares the values
+    for _ in range(4):
+        render[(8, 8), (16, 16)](grid, result, camera.position, camera.rotation, sp, li, pl, 0.0, 0.6, 0.3, 3, False)
+    assert r.stats()["launches_settled"] - after["launches_settled"] == 4
+
+
+@pytest.mark.parametrize("case", ["default_128_d3", "tilted_planes_48", "stoch_48_spp4"])
+def test_ray_counters_match_oracle(renderer, oracle, case):
+    """rt_get_stats: the counting instantiation reports the queries it traces; together with the shadow queries it
+    skips (answer unused, trace.py:101) they are exactly the reference algorithm's counts (oracle counters)."""
+    from python_ray_tracer_amd import _lib as L
+    g = load_frame(case)
+    w, h, rg = _setup(renderer, g)
+    plain8, plain32 = _render(renderer, g)
+    renderer.reset_stats()
+    u8, f32 = _render(renderer, g, flags=L.RT_FLAG_COUNT_RAYS)
+    assert np.array_equal(u8, plain8) and np.array_equal(f32, plain32)
+    st = renderer.stats()
+    ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]),
+                        float(g["lamb"]), float(g["refl"]), int(g["depth"]), int(g["aa"]), raygen=rg, refl_pow=g["refl_pow"],
+                        want=(), spp=int(g["spp"]) if "spp" in g else 0, seed=int(g["seed"]) if "seed" in g else 1)["counters"]
+    assert st["closest_queries"] == ref["closest"] and st["hits"] == ref["hits"]
+    assert st["shadow_traced"] + st["shadow_skipped"] == ref["shadow"]
+    assert 0 < st["shadow_traced"] <= ref["shadow"]
+    _render(renderer, g, flags=L.RT_FLAG_COUNT_RAYS)              # counters accumulate until reset
+    assert renderer.stats()["closest_queries"] == 2 * ref["closest"]
+    renderer.reset_stats()
+    assert renderer.stats()["closest_queries"] == 0
 
 
 def test_moving_camera_over_streams(renderer, oracle):

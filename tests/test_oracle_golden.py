@@ -109,3 +109,33 @@ def test_typed_bias_variant_differs_only_slightly(oracle):
             float(g["refl"]), int(g["depth"]), False)
     a = oracle.render(*args, **kw)["f64"]; b = oracle.render(*args, flags=oracle.FLAG_TYPED_BIAS, **kw)["f64"]
     assert not np.array_equal(a, b) and np.abs(a - b).max() < 1e-5
+
+
+def test_closest_hit_tie_rule_cases(oracle):
+    """tests/golden/tie_break.npz (reference output, oracle/gen_golden.py:gen_tie_cases): scenes where two spheres have
+    DIFFERENT numerators whose quotients round to the SAME distance, so the reference's rule (smallest t, then lowest
+    index, trace.py:26) differs from "smallest numerator wins".  The oracle follows the reference literally; the
+    fixture must really contain such pixels (a min-numerator evaluation, replayed here in numpy, picks other spheres)."""
+    g = np.load(os.path.join(GOLDEN, "tie_break.npz"))
+    for ci in range(int(g["n"])):
+        pl, o, sp = g[f"pixel_loc_{ci}"], g[f"cam_origin_{ci}"], g[f"spheres_{ci}"]
+        side = pl.shape[1]
+        ref = oracle.render(side, side, o, np.eye(3), sp, np.zeros((3, 0), np.float32), np.zeros((9, 0), np.float32),
+                            1.0, 0.0, 0.0, 0, False, pixel_loc=pl, want=("u8", "f64"))
+        assert np.array_equal(ref["u8"], g[f"u8_{ci}"]) and np.array_equal(ref["f64"], g[f"rgb64_{ci}"])
+        # replay: which sphere would "smallest numerator, lowest index on equal numerators" choose?
+        P = pl.reshape(3, -1)
+        nrm = lambda v: v / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])      # noqa: E731
+        R = nrm(nrm(P)); a = (R[0] * R[0] + R[1] * R[1]) + R[2] * R[2]
+        N = []
+        for k in range(sp.shape[1]):
+            L = o - sp[0:3, k].astype(np.float64)
+            s_ = (L[0] * R[0] + L[1] * R[1]) + L[2] * R[2]
+            cc = ((L[0] * L[0] + L[1] * L[1]) + L[2] * L[2]) - np.float64(sp[3, k] * sp[3, k])
+            q = np.sqrt(s_ * s_ - a * cc)
+            n = -s_ - q
+            N.append(np.where(n > 0, n, -s_ + q))
+        naive = np.argmin(np.array(N), axis=0)                       # first index among the smallest numerators
+        red_naive = sp[4, naive].astype(np.float64).reshape(side, side)      # amb = 1: the pixel's R is the sphere's R
+        differs = (red_naive != g[f"rgb64_{ci}"][0]).sum()
+        assert differs == int(g[f"disagreeing_{ci}"]) and differs >= 30
