@@ -3,18 +3,24 @@
 
 A step = one frame of BASELINE.json's headline configuration (configs[1]: 1920x1080, 8 spheres +
 1 plane, 3 lights, depth 3, no AA; synthetic scene = the reference's default scene + 2 spheres).
-With N > 1 ranks (one process per GPU, launched by torch.distributed.run) the SAME frame is cut into
-N column slabs, each rank renders its slab, and the uint8 frames are assembled on rank 0 by RCCL
-gathers (the slabs of several consecutive frames per gather) — total work is fixed, so `scaling` is "strong".
+With N > 1 ranks (one process per GPU, launched by torch.distributed.run — or by this script itself
+when it is started plainly with --gpus N) the SAME frame is cut into N column slabs, each rank renders
+its slab, and the uint8 frames are assembled on rank 0 by RCCL gathers (the slabs of several consecutive
+frames per gather) — total work is fixed, so `scaling` is "strong".
 Frames are queued round-robin on a few streams so that consecutive frames overlap.
 
 Inputs (scene, camera) are resident on the device before the timed region; outputs stay in HBM.
+Before the warm-up the device is pre-heated for a fixed WALL TIME with real frames (`preheat_ms`): the
+engine clock needs a few hundred milliseconds of load to reach its steady state, and `--steps 20` on a
+cold device times 2.6 ms of it.  `--steps` / `--warmup` are honoured exactly as passed.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,6 +35,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ROUND = "r02"           # profiles/traffic_<ROUND>.json, profiles/valu_<ROUND>.json (written by tools/profile_round.py)
 
 
 def cpu_baseline(wl, rays_per_frame, min_wall_s=2.5):
@@ -53,6 +60,27 @@ def cpu_baseline(wl, rays_per_frame, min_wall_s=2.5):
             "frame_ms": round(dt / frames * 1e3, 2)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (before this
+    process has touched the GPU) and pass their output and exit code through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def stamped(path, so_sha):
+    """A profile-derived constant file applies only to the library build it was measured on."""
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d if d.get("so_sha256") == so_sha else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,23 +90,28 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="streams the frames are queued on round-robin (1 = strictly serial)")
     ap.add_argument("--frames-per-gather", type=int, default=8, help="N > 1: frames whose slabs travel to rank 0 in one gather")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 exchange structure on one GPU (world-size-1 RCCL group)")
+    ap.add_argument("--preheat-ms", type=float, default=300.0, help="wall time of real frames rendered before the warm-up (clock ramp)")
+    ap.add_argument("--no-step-events", action="store_true", help="do not record one HIP event per step (drops the per-step statistics)")
+    ap.add_argument("--no-serial", action="store_true", help="skip the one-stream pass behind the timed region (roofline.serial)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point rt_render (host_path_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--balance-rounds", type=int, default=4, help="N > 1: rounds of measured-time slab balancing before the run (0 = equal-width slabs)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(spawn_ranks(a.gpus))
         a.gpus = world
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import python_ray_tracer_amd as pkg
-    from python_ray_tracer_amd import workloads
-    from python_ray_tracer_amd.distributed import slab_bounds
+    from python_ray_tracer_amd import workloads, _lib
+    from python_ray_tracer_amd.distributed import slab_bounds, SequencePipeline
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -93,7 +126,20 @@ def main():
     r.set_camera(cam.position, cam.rotation)
     r.set_raygen(w, h, *cam.raygen())
     params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"])
-    x0, x1 = slab_bounds(w, world, rank)
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Column slabs: equal widths to start with; with N > 1 the boundaries are then moved until the ranks' MEASURED slab
+    # times agree (sky columns are cheap, the sphere cluster is not: equal widths leave the slowest rank 23 % above
+    # the mean at N = 8, and the frame is as slow as its slowest slab).  Setup, like the uploads: not timed.
+    bounds = [slab_bounds(w, world, q) for q in range(world)]
+    balance = None
+    if world > 1 and a.balance_rounds > 0:
+        bounds, balance = balance_slabs(r, params, w, h, world, rank, dev, dist, torch, max(1, a.streams), a.balance_rounds)
+    x0, x1 = bounds[rank]
     ws = x1 - x0
     # python_ray_tracer_amd.distributed.SequencePipeline does the choreography (tests/test_distributed_cpu.py runs the
     # same class on gloo): frames are queued round-robin on `--streams` torch-owned, non-default streams (default 3),
@@ -103,7 +149,6 @@ def main():
     # to rank 0 in ONE gather (a collective costs tens of microseconds however small it is; a 240-column slab
     # renders in less), issued on a separate stream, two exchanges in flight: batch i is gathered and assembled
     # while batch i+1 renders.
-    from python_ray_tracer_amd.distributed import SequencePipeline
     NS = max(1, a.streams)
     use_gather = world > 1 or a.force_gather
     if a.force_gather and world == 1:
@@ -116,7 +161,8 @@ def main():
         nonlocal frame
         frame = frames[count - 1]
     pipe = SequencePipeline(w, h, ws, dev, dist if use_gather else None, dst=0, streams=NS, frames_per_gather=F,
-                            want_f32=True, on_frames=on_frames)
+                            want_f32=True, on_frames=on_frames, bounds=bounds if use_gather else None)
+    PS = pipe.plane_stride                              # slabs are stored padded to the widest rank's width
     assert all(pipe.stream_handle(i) for i in range(NS)), "expected non-default stream handles"
 
     ptrs = {}                                           # tensor view -> device address, looked up once per buffer
@@ -125,25 +171,46 @@ def main():
         k = id(u8)
         if k not in ptrs:
             ptrs[k] = (u8.data_ptr(), f32.data_ptr())
-        r.render_device(params, x0, x1, ptrs[k][0], ptrs[k][1], ws * h, stream)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        r.render_device(params, x0, x1, ptrs[k][0], ptrs[k][1], PS, stream)
 
     for _ in range(2):                                  # setup, like the uploads above: the first two launches of a geometry
         launch(pipe.u8v[0][0], pipe.f32v[0][0], pipe.stream_handle(0))
     torch.cuda.synchronize()                            # build the cull tables, measure tile costs, build the dispatch order
+
+    # -- pre-heat: real frames for a fixed wall time (every rank the same number of frames: with N > 1 the frames
+    # carry collectives).  A short calibration burst prices a frame, the count follows from it.
+    t_pre = time.perf_counter()
+    preheat_frames = 0
+    if a.preheat_ms > 0:
+        cal = 4 * F * NS
+        tc = time.perf_counter()
+        for _ in range(cal):
+            pipe.submit(launch)
+        pipe.drain()
+        per = (time.perf_counter() - tc) / cal
+        n = int(max(0.0, a.preheat_ms * 1e-3 - (time.perf_counter() - t_pre)) / max(per, 1e-6))
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        n = min(int(cnt[0]), 2_000_000)
+        for _ in range(n):
+            pipe.submit(launch)
+        pipe.drain()
+        preheat_frames = cal + n
+    preheat_ms = (time.perf_counter() - t_pre) * 1e3
+
     for i in range(a.warmup):
         pipe.submit(launch)
     pipe.drain()
-    # One HIP event pair per launch stream around the whole timed region: elapsed / (launches on that stream) is
-    # the mean duration of one launch as rocprofv3's kernel trace sees it (launches on one stream run back to back;
-    # with N > 1 it also holds whatever waiting for a free slab costs) — NS of them are in flight at a time.
+    # One HIP event per launch stream in front of the timed region and one behind every step, on the stream the
+    # step's kernel was launched on (torch.cuda.Event on a stream object records on THAT stream, not on torch's
+    # current one).  Launches of one stream run back to back, so the gap between consecutive events of a stream is
+    # the duration of one launch as rocprofv3's kernel trace sees it; the gaps between consecutive completions over
+    # all streams are the frame periods.  NS launches are in flight at a time.
+    step_events = not a.no_step_events
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)] if step_events else []
     fence()
     t0 = time.perf_counter()
     first_pos = pipe.n
@@ -151,6 +218,8 @@ def main():
         ev0[s_].record(pipe.streams[s_])
     for i in range(a.steps):
         pipe.submit(launch)
+        if step_events:
+            evs[i].record(pipe.streams[(first_pos + i) % NS])
     t_submitted = time.perf_counter()
     for s_ in range(NS):
         ev1[s_].record(pipe.streams[s_])
@@ -160,8 +229,19 @@ def main():
     launches = [sum(1 for i in range(first_pos, first_pos + a.steps) if i % NS == s_) for s_ in range(NS)]
     spans = [ev0[s_].elapsed_time(ev1[s_]) / launches[s_] for s_ in range(NS) if launches[s_]]
     kernel_ms = sum(spans) / max(len(spans), 1)
+    per_launch, periods = [], []
+    if step_events:
+        last = {s_: ev0[s_] for s_ in range(NS)}
+        done = []
+        for i in range(a.steps):
+            s_ = (first_pos + i) % NS
+            per_launch.append(last[s_].elapsed_time(evs[i]))
+            last[s_] = evs[i]
+            done.append(ev0[0].elapsed_time(evs[i]))     # completion time of step i on a common clock
+        done.sort()
+        periods = [b - c for b, c in zip(done[1:], done[:-1])]
     if not use_gather:
-        frame = pipe.last_slab()
+        frame = pipe.last_slab()[:, :ws]
 
     t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -183,15 +263,57 @@ def main():
         alg_bytes = ws * h * 15 + 4 * (7 * S + 3 * L + 9 * P) + 96
         kernel_eff = kernel_ms_max / NS                  # NS launches are in flight at a time
         achieved = alg_bytes / (kernel_eff * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
-        if world == 1 and name == workloads.HEADLINE and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        so_sha = hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()
+        headline1 = world == 1 and name == workloads.HEADLINE
+        tr = stamped(os.path.join(REPO, "profiles", f"traffic_{ROUND}.json"), so_sha) if headline1 else None
+        traffic = tr.get("hbm_bytes_per_launch") if tr else None
         frame_host = frame.cpu().numpy()
         check = None
         gpath = os.path.join(REPO, "tests", "golden", "frame_c2_1080p.npz")
         if name == workloads.HEADLINE and os.path.exists(gpath):
             check = hashlib.sha256(frame_host.tobytes()).hexdigest() == str(np.load(gpath)["sha256_u8"])
+
+        # -- what the kernel really traced (counting instantiation, one frame, outside the timed region)
+        traced = None
+        if world == 1:
+            r.reset_stats()
+            pc = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"],
+                          flags=_lib.RT_FLAG_COUNT_RAYS)
+            r.render_device(pc, x0, x1, pipe.u8v[0][0].data_ptr(), pipe.f32v[0][0].data_ptr(), PS, pipe.stream_handle(0))
+            torch.cuda.synchronize()
+            st = r.stats()
+            traced = {"closest_queries": st["closest_queries"], "shadow_traced": st["shadow_traced"],
+                      "shadow_skipped_answer_unused": st["shadow_skipped"], "hits": st["hits"],
+                      "total_traced": st["closest_queries"] + st["shadow_traced"]}
+
+        # -- the same frames on ONE stream, strictly one after another: per-launch duration = frame period, so the
+        # roofline fraction follows from the plain formula (bytes / duration / peak)
+        serial = None
+        if world == 1 and not a.no_serial:
+            ns = max(a.steps, 200)
+            sh = pipe.stream_handle(0)
+            u8p, f32p = pipe.u8v[0][0].data_ptr(), pipe.f32v[0][0].data_ptr()
+            for _ in range(20):
+                r.render_device(params, x0, x1, u8p, f32p, PS, sh)
+            torch.cuda.synchronize()
+            se = [torch.cuda.Event(enable_timing=True) for _ in range(ns + 1)]
+            se[0].record(pipe.streams[0])
+            for i in range(ns):
+                r.render_device(params, x0, x1, u8p, f32p, PS, sh)
+                se[i + 1].record(pipe.streams[0])
+            torch.cuda.synchronize()
+            durs = [se[i].elapsed_time(se[i + 1]) for i in range(ns)]
+            mean = se[0].elapsed_time(se[ns]) / ns
+            serial = {"launches": ns, "kernel_ms": round(mean, 5), "kernel_ms_median": round(statistics.median(durs), 5),
+                      "kernel_ms_min": round(min(durs), 5), "achieved": round(alg_bytes / (mean * 1e-3) / 1e9, 3),
+                      "frac": round(alg_bytes / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                      "note": "one stream, launches strictly back to back: achieved = algorithmic_bytes / kernel_ms, the plain formula"}
+
+        # -- the host-buffer entry point (what an unchanged main.py sees: launch + copy_to_host); never `value`
+        host_path = None
+        if world == 1 and not a.no_host_path:
+            host_path = host_path_ms(r, wl, np)
+
         out = {
             "metric": "Mrays/sec + frame time (ms) at 1920x1080, 8 spheres, depth=3",
             "value": round(rays_per_frame / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
@@ -199,28 +321,46 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "width": w, "height": h, "spheres": S, "planes": P, "lights": L,
                        "depth": wl["depth"], "aa": bool(wl["aa"]), "rays_per_frame": rays_per_frame,
+                       "rays_per_frame_is": "the reference algorithm's query count for this frame (closest-hit + shadow queries, "
+                                            "oracle counters); rays_traced_per_frame is what the kernel traces",
+                       "rays_traced_per_frame": traced["total_traced"] if traced else None,
                        "primary_rays_per_frame": w * h, "outputs": "uint8 (3,w,h) frame + float32 (3,w,h) pre-clip RGB",
                        "streams": NS,
                        "parallelism": f"column slabs x{world}, frames queued round-robin on {NS} stream(s)" + (f", one RCCL gather of the uint8 slabs of {F} frames to rank 0 per {F} steps, overlapped with the next steps' renders" if use_gather else "")},
-            "frame_ms": round(ms_per_step, 5), "frame_latency_ms": round(kernel_ms_max, 5),
+            "frame_ms": round(ms_per_step, 5),
+            "frame_ms_median": round(statistics.median(periods), 5) if periods else None,
+            "frame_ms_min": round(min(periods), 5) if periods else None,
+            "frame_latency_ms": round(kernel_ms_max, 5),
+            "launch_ms_median": round(statistics.median(per_launch), 5) if per_launch else None,
+            "launch_ms_min": round(min(per_launch), 5) if per_launch else None,
+            "preheat_ms": round(preheat_ms, 1), "preheat_frames": preheat_frames,
             "host_submit_ms_per_step": round((t_submitted - t0) / a.steps * 1e3, 5),
             "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
+            "traced_mrays_per_s": round(traced["total_traced"] / (dt / a.steps) / 1e6, 2) if traced else None,
+            "rays_traced": traced,
             "frame_matches_reference_sha256": check,
+            "slab_balance": balance,
+            "host_path_ms": host_path,
+            "library_sha256": so_sha,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "rt::render_kernel", "kernel_ms": round(kernel_ms_max, 5), "launches_in_flight": NS,
                          "kernel_ms_per_launch_effective": round(kernel_eff, 5), "algorithmic_bytes": alg_bytes,
+                         "per_launch": {"achieved": round(alg_bytes / (kernel_ms_max * 1e-3) / 1e9, 3),
+                                        "frac": round(alg_bytes / (kernel_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                        "note": "plain formula on the overlapped launches of the timed region: algorithmic_bytes / kernel_ms"},
+                         "serial": serial,
                          "note": "kernel_ms = mean duration of one launch (HIP event pair per stream / launches on it; what "
                                  "rocprofv3's kernel trace shows); launches_in_flight of them overlap, so achieved = "
-                                 "launches_in_flight x algorithmic_bytes / kernel_ms.  float64 VALU-bound by construction "
+                                 "launches_in_flight x algorithmic_bytes / kernel_ms (= bytes per frame period); `per_launch` and "
+                                 "`serial` follow from the plain formula.  float64 VALU-bound by construction "
                                  "(about 15 B and ~2 kflop per pixel): the HBM fraction is reported because BASELINE.json's "
                                  "north_star asks for it, not because HBM limits this kernel"},
         }
-        # The bound that actually limits this kernel: VALU instruction issue.  Static per-launch counts from the
-        # rocprofv3 op-mix pass (profiles/valu_r01.json); achieved = float64 FLOP / kernel time vs the fp64 vector peak.
-        vpath = os.path.join(REPO, "profiles", "valu_r01.json")
-        if world == 1 and name == workloads.HEADLINE and os.path.exists(vpath):
-            v = json.load(open(vpath))
+        # The bound that actually limits this kernel: VALU instruction issue.  Per-launch counts from the rocprofv3
+        # op-mix pass of THIS library build (profiles/valu_<round>.json carries the build's SHA-256; another build -> null).
+        v = stamped(os.path.join(REPO, "profiles", f"valu_{ROUND}.json"), so_sha) if headline1 else None
+        if v:
             out["valu"] = {"fp64_flop_per_launch": v["fp64_flop_per_launch"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"],
                            "achieved_fp64_tflops": round(v["fp64_flop_per_launch"] / (kernel_eff * 1e-3) / 1e12, 3),
                            "peak_fp64_vector_tflops": 78.6, "frac": round(v["fp64_flop_per_launch"] / (kernel_eff * 1e-3) / 78.6e12, 4),
@@ -228,13 +368,70 @@ def main():
                            "issue_bound_ms": round(v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) * 1e3, 5),
                            "issue_frac": round(v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) / (kernel_eff * 1e-3), 4),
                            "note": v["note"]}
+        else:
+            out["valu"] = None
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, rays_per_frame)
         print(json.dumps(out), flush=True)
+    pipe.close(r)
     r.close()
     if world > 1 or a.force_gather:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def balance_slabs(r, params, w, h, world, rank, dev, dist, torch, ns, rounds, frames=48):
+    """Every rank times its own slab (frames round-robin on `ns` streams, as in the run), the times are all-gathered
+    and python_ray_tracer_amd.distributed.SlabBalancer moves the boundaries; the last round only measures."""
+    from python_ray_tracer_amd.distributed import SlabBalancer
+    bal = SlabBalancer(w, world)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    u8 = [torch.empty(3 * w * h, dtype=torch.uint8, device=dev) for _ in range(ns)]
+    f32 = [torch.empty(3 * w * h, dtype=torch.float32, device=dev) for _ in range(ns)]
+    history = []
+    for it in range(rounds + 1):
+        a_, b_ = bal.bounds[rank]
+
+        def burst(n):
+            for i in range(n):
+                r.render_device(params, a_, b_, u8[i % ns].data_ptr(), f32[i % ns].data_ptr(), (b_ - a_) * h, streams[i % ns].cuda_stream)
+        burst(2); torch.cuda.synchronize()                # measure the tile costs, build the dispatch order
+        burst(2 * ns); torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        burst(frames)
+        torch.cuda.synchronize()
+        mine = torch.tensor([(time.perf_counter() - t0) / frames * 1e3], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        times = [float(t[0]) for t in allt]
+        history.append({"bounds": [list(b) for b in bal.bounds], "slab_ms": [round(t, 5) for t in times],
+                        "max_over_mean": round(max(times) / (sum(times) / world), 4)})
+        if it < rounds:
+            bal.update(times)
+    for s_ in streams:
+        r.stream_forget(s_.cuda_stream)
+    best = min(range(len(history)), key=lambda i: history[i]["max_over_mean"])
+    bounds = [tuple(b) for b in history[best]["bounds"]]
+    return bounds, {"equal_width": history[0], "chosen": history[best], "rounds": rounds}
+
+
+def host_path_ms(r, wl, np, frames=40):
+    """rt_render into host memory (launch + device-to-host copy + sync per frame), uint8 frame only and with the
+    float32 buffer as well; pageable numpy arrays and pinned arrays from the library (Renderer.host_array)."""
+    out = {}
+    for label, want32 in (("u8", False), ("u8_f32", True)):
+        for mem in ("pageable", "pinned"):
+            bufs = r.host_arrays(want32, pinned=(mem == "pinned"))
+            for _ in range(3):
+                r.render_into(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], *bufs, spp=wl["spp"], seed=wl["seed"])
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                r.render_into(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], *bufs, spp=wl["spp"], seed=wl["seed"])
+            out[f"{label}_{mem}"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+            r.release_host_arrays(bufs)
+    out["note"] = "ms per frame of rt_render (kernel + D2H + sync), PCIe-inclusive; never `value`"
+    return out
 
 
 if __name__ == "__main__":

@@ -164,6 +164,14 @@ int rt_set_pixel_loc(rt_ctx *ctx, const double *pixel_loc, int w, int h);
  *   out_f32 : float32 (3, x1-x0, h) the (R,G,B) handed to clip_color_vector (kernels.py:69),
  *             true channel order, unclamped; or NULL */
 int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32);
+/* (Frames of half a megapixel and more are rendered in four column chunks whose copies to the host overlap the
+ * rendering of the chunks behind them; the result is the same bytes.) */
+
+/* Page-locked host memory for rt_render's outputs: the device-to-host copy of a frame then runs at the link's rate
+ * (with pageable memory the runtime stages it).  Any host pointer is accepted by rt_render; these are an offer.
+ * (The reference's `result.copy_to_host()` allocates its own pageable array, main.py:51.) */
+int rt_host_alloc(rt_ctx *ctx, size_t bytes, void **hptr);
+int rt_host_free(rt_ctx *ctx, void *hptr);
 
 /* The same launch into DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = the
  * context's own stream).  Element [c, x, y] (x0 <= x < x1) is stored at

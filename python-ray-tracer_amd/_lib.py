@@ -56,6 +56,8 @@ PROTOTYPES = {
     "rt_set_tile_stats": (C.c_int, [_vp, _vp]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(rt_stats)]),
     "rt_reset_stats": (C.c_int, [_vp]),
+    "rt_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rt_host_free": (C.c_int, [_vp, _vp]),
     "rt_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rt_free": (C.c_int, [_vp, _vp]),
     "rt_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

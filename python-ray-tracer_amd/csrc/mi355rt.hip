@@ -26,9 +26,14 @@ struct Buf {
 
 }  // namespace
 
+#define RT_FEEDBACK_SLOTS 8
+#define RT_RENDER_CHUNKS 4
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr, copy_stream = nullptr;   // rt_render's chunk pipeline (created on first use)
+    hipEvent_t chunk_ev[RT_RENDER_CHUNKS] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
     int S = 0, P = 0, L = 0;
@@ -62,7 +67,9 @@ struct rt_ctx {
         hipEvent_t handover = nullptr; // recorded on the owner's stream when another stream takes the buffers over
         std::vector<std::pair<hipStream_t, hipEvent_t>> readers;   // other streams dispatching in the settled order
         std::vector<hipEvent_t> spare;
-    } fb;
+        unsigned long long stamp = 0; // last use (the least recently used geometry is replaced)
+    } fbs[RT_FEEDBACK_SLOTS];         // one per launch geometry in use: slabs, chunks and AA modes do not evict each other
+    unsigned long long fb_stamp = 0;
     rt_stats stats = {};              // host-side launch counters (the ray counters live in `counts`)
     Buf counts;                       // 4 x uint64 on the device: ray counters of RT_FLAG_COUNT_RAYS launches
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
@@ -279,7 +286,16 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = ctx->h; key.aa = k.aa; key.depth = k.depth;
     key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw;
-    rt_ctx::Feedback &f = ctx->fb;
+    rt_ctx::Feedback *fsel = nullptr;
+    for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
+    if (!fsel) {                                               // a free slot, else the least recently used geometry
+        for (auto &c : ctx->fbs) if (!fsel || (!c.key.valid && fsel->key.valid) || (c.key.valid == fsel->key.valid && c.stamp < fsel->stamp)) fsel = &c;
+    }
+    rt_ctx::Feedback &f = *fsel;
+    if (feedback && !f.done) {
+        RT_HIP(ctx, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&f.handover, hipEventDisableTiming));
+    }
     // Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile
     // order, once from longest-first order): the costs are the same again, so the launch neither measures nor
     // rebuilds -- it just dispatches in that order, on any stream (frames of a static scene can be pipelined
@@ -291,6 +307,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     // plain order and leaves them alone.
     bool measure = false;
     if (settled) {
+        f.stamp = ++ctx->fb_stamp;
         k.order = (const unsigned *)f.order.p;
         if (stream != f.stream) {
             bool known = false;
@@ -308,6 +325,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
     }
     if (measure) {
+        f.stamp = ++ctx->fb_stamp;
         // Taking the buffers over from another stream: hipEventQuery(f.done) only proves that the owner's last
         // ORDER KERNEL has finished.  Settled launches the owner queued after it still read `order` (the owner is
         // not in f.readers), so this stream waits for everything the owner has queued so far.
@@ -384,9 +402,7 @@ int rt_create(rt_ctx **out, int device)
     ctx->device = device;
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-        (s = hipEventCreateWithFlags(&ctx->fb.done, hipEventDisableTiming)) != hipSuccess ||
-        (s = hipEventCreateWithFlags(&ctx->fb.handover, hipEventDisableTiming)) != hipSuccess) {
+        (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess) {
         std::string m = std::string("context setup: ") + hipGetErrorString(s);
         delete ctx;
         return fail(nullptr, RT_ERR_HIP, m);
@@ -400,18 +416,23 @@ int rt_destroy(rt_ctx *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->fb.hist, &ctx->fb.slot, &ctx->fb.order, &ctx->counts})
+    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->counts})
         if (b->p) (void)hipFree(b->p);
+    for (auto &f : ctx->fbs) {
+        for (Buf *b : {&f.hist, &f.slot, &f.order}) if (b->p) (void)hipFree(b->p);
+        for (auto &r : f.readers) (void)hipEventDestroy(r.second);
+        for (hipEvent_t e : f.spare) (void)hipEventDestroy(e);
+        if (f.done) (void)hipEventDestroy(f.done);
+        if (f.handover) (void)hipEventDestroy(f.handover);
+    }
     for (auto &t : ctx->tables) {
         if (t.buf.p) (void)hipFree(t.buf.p);
         if (t.built) (void)hipEventDestroy(t.built);
         for (auto &r : t.readers) (void)hipEventDestroy(r.second);
     }
     for (hipEvent_t e : ctx->spare_events) (void)hipEventDestroy(e);
-    for (auto &r : ctx->fb.readers) (void)hipEventDestroy(r.second);
-    for (hipEvent_t e : ctx->fb.spare) (void)hipEventDestroy(e);
-    if (ctx->fb.done) (void)hipEventDestroy(ctx->fb.done);
-    if (ctx->fb.handover) (void)hipEventDestroy(ctx->fb.handover);
+    for (hipStream_t st : {ctx->stream2, ctx->copy_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : ctx->chunk_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -606,14 +627,65 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
     const size_t npx = (size_t)(x1 - x0) * ctx->h;
     if (out_u8 && (rc = ensure(ctx, ctx->u8, 3 * npx)) != RT_OK) return rc;
     if (out_f32 && (rc = ensure(ctx, ctx->f32, 3 * npx * sizeof(float))) != RT_OK) return rc;
-    if ((params->flags & RT_FLAG_U8_HWC) && out_f32)
+    const bool hwc = (params->flags & RT_FLAG_U8_HWC) != 0;
+    if (hwc && out_f32)
         return fail(ctx, RT_ERR_BAD_ARG, "RT_FLAG_U8_HWC: request the uint8 image and the float32 buffer in separate calls");
-    rc = launch(ctx, params, x0, x1, out_u8 ? ctx->u8.p : nullptr, out_f32 ? ctx->f32.p : nullptr,
-                (params->flags & RT_FLAG_U8_HWC) ? (int64_t)(x1 - x0) : (int64_t)npx, ctx->stream);
-    if (rc != RT_OK) return rc;
-    if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8, ctx->u8.p, 3 * npx, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32, ctx->f32.p, 3 * npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // Large planar frames are rendered in RT_RENDER_CHUNKS column chunks, alternately on two streams (consecutive
+    // launches overlap), and every chunk's planes start their way to the host (third stream, behind an
+    // event) while the following chunks still render: the copy of a 1080p frame costs about as much as rendering it,
+    // and this hides all of it but the last chunk's.  (main.py:41-51: launch, then copy_to_host.)
+    const int tiles = (x1 - x0 + rt::TILE - 1) / rt::TILE;
+    if (hwc || npx < (1u << 19) || tiles < 4 * RT_RENDER_CHUNKS) {
+        rc = launch(ctx, params, x0, x1, out_u8 ? ctx->u8.p : nullptr, out_f32 ? ctx->f32.p : nullptr,
+                    hwc ? (int64_t)(x1 - x0) : (int64_t)npx, ctx->stream);
+        if (rc != RT_OK) return rc;
+        if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8, ctx->u8.p, 3 * npx, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32, ctx->f32.p, 3 * npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    if (!ctx->copy_stream) {
+        RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (auto &e : ctx->chunk_ev) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int cx[RT_RENDER_CHUNKS + 1];
+    for (int c = 0; c <= RT_RENDER_CHUNKS; ++c) cx[c] = std::min(x1, x0 + (int)((long long)tiles * c / RT_RENDER_CHUNKS) * rt::TILE);
+    for (int c = 0; c < RT_RENDER_CHUNKS; ++c) {
+        hipStream_t s = (c & 1) ? ctx->stream2 : ctx->stream;
+        const size_t off = (size_t)(cx[c] - x0) * ctx->h;
+        rc = launch(ctx, params, cx[c], cx[c + 1], out_u8 ? (uint8_t *)ctx->u8.p + off : nullptr,
+                    out_f32 ? (float *)ctx->f32.p + off : nullptr, (int64_t)npx, s);
+        if (rc != RT_OK) return rc;
+        RT_HIP(ctx, hipEventRecord(ctx->chunk_ev[c], s));
+    }
+    for (int c = 0; c < RT_RENDER_CHUNKS; ++c) {
+        const size_t off = (size_t)(cx[c] - x0) * ctx->h, n = (size_t)(cx[c + 1] - cx[c]) * ctx->h;
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_ev[c], 0));
+        for (int pl = 0; pl < 3; ++pl) {
+            if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8 + pl * npx + off, (uint8_t *)ctx->u8.p + pl * npx + off, n, hipMemcpyDeviceToHost, ctx->copy_stream));
+            if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32 + pl * npx + off, (float *)ctx->f32.p + pl * npx + off, n * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
+    }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return RT_OK;
+}
+
+int rt_host_alloc(rt_ctx *ctx, size_t bytes, void **hptr)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!hptr || bytes == 0) return fail(ctx, RT_ERR_BAD_ARG, "rt_host_alloc: NULL out-pointer or zero size");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return RT_OK;
+}
+
+int rt_host_free(rt_ctx *ctx, void *hptr)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!hptr) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipHostFree(hptr));
     return RT_OK;
 }
 
@@ -681,12 +753,13 @@ int rt_stream_create(rt_ctx *ctx, void **stream)
 static int forget_stream(rt_ctx *ctx, hipStream_t stream)
 {
     RT_HIP(ctx, hipStreamSynchronize(stream));
-    rt_ctx::Feedback &f = ctx->fb;
-    for (size_t i = 0; i < f.readers.size();) {
-        if (f.readers[i].first == stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }
-        else ++i;
+    for (auto &f : ctx->fbs) {
+        for (size_t i = 0; i < f.readers.size();) {
+            if (f.readers[i].first == stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }
+            else ++i;
+        }
+        if (f.stream == stream) f.stream = ctx->stream;         // its work is complete: anyone may take over
     }
-    if (f.stream == stream) f.stream = ctx->stream;             // its work is complete: anyone may take over
     for (auto &t : ctx->tables)
         for (size_t i = 0; i < t.readers.size();) {
             if (t.readers[i].first == stream) { ctx->spare_events.push_back(t.readers[i].second); t.readers.erase(t.readers.begin() + (long)i); }

@@ -36,7 +36,7 @@ class DeviceNDArray:
         self._host = host            # values at creation time (inputs) / last copied-back values
         self._dptr = None            # device buffer, allocated when a launch writes to this array
         self._renderer = None
-        self._dirty = False          # device buffer newer than _host
+        self._dirty = False          # a launch has written the device buffer: it, not _host, holds the contents
         self.version = 0             # bumped whenever the contents change (launch caches key on it)
         self.serial = next(_serials) # process-unique identity (id() values are reused after garbage collection)
 
@@ -52,10 +52,13 @@ class DeviceNDArray:
         return self._dptr
 
     def copy_to_host(self):
+        """A new host array with the current contents (numba's semantics).  Once a launch has written the device
+        buffer, that buffer is the truth: one device-to-host copy straight into the array that is returned."""
         if self._dirty:
+            out = np.empty(self._host.shape, self._host.dtype)
             self._renderer.sync()
-            self._renderer.d2h(self._host, self._dptr)
-            self._dirty = False
+            self._renderer.d2h(out, self._dptr)
+            return out
         return self._host.copy()
 
     def __array__(self, dtype=None, copy=None):

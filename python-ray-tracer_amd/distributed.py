@@ -3,11 +3,11 @@ column slab per rank (every pixel is independent — kernels.py:10-26 — and th
 each rank renders its slab with its own x offset, and the frame is assembled on rank 0 by a gather
 (RCCL over xGMI when the process group is `nccl`; `gloo` on CPU for tests).
 
-With equal slabs (w divisible by 8*world, e.g. 1920 on 1/2/4/8 GPUs) the exchange is ONE gather per
-frame into a (world, 3, ws, h) staging buffer followed by one strided device copy into the (3,w,h)
-frame; it can be issued asynchronously so that frame i is gathered while frame i+1 is rendered
-(FrameGatherer, double-buffered).  Ragged slabs fall back to per-plane point-to-point transfers
-straight into the frame's contiguous column runs.
+The exchange is ONE gather per batch of frames into a (world, F, 3, ws, h) staging buffer followed by a
+strided device copy into the (F,3,w,h) frames; it is issued asynchronously so that batch i is gathered while
+batch i+1 is rendered (FrameGatherer, double-buffered).  Slabs may be unequal — cost-weighted boundaries
+(weighted_slab_bounds, SlabBalancer) or a width that does not divide: every rank then renders into a buffer
+padded to the widest slab, so that it is still one gather.
 """
 
 
@@ -23,6 +23,61 @@ def slab_bounds(w, world_size, rank, align=8):
     return min(t0 * align, w), min(t1 * align, w)
 
 
+def weighted_slab_bounds(tile_col_cost, w, world_size, align=8):
+    """Tile-aligned contiguous column slabs of (nearly) equal COST instead of equal width.
+
+    tile_col_cost[i] > 0 is the cost of tile column i (`align` pixel columns; e.g. column sums of the per-tile
+    cycles rt_set_tile_stats records, or the density SlabBalancer refines from measured slab times).  Every pixel
+    is independent (kernels.py:10-26), so any partition yields the same frame; only the ranks' finishing times
+    depend on it.  Boundary r is placed where the running cost passes r/world of the total; every rank keeps at
+    least one tile column while there are enough of them.  Returns [(x0, x1)] * world_size."""
+    cost = [max(float(c), 0.0) for c in tile_col_cost]
+    tiles = (w + align - 1) // align
+    if len(cost) != tiles:
+        raise ValueError(f"expected {tiles} tile-column costs, got {len(cost)}")
+    total = sum(cost)
+    if not total > 0.0:
+        return [slab_bounds(w, world_size, r, align) for r in range(world_size)]
+    cuts, run, i = [0], 0.0, 0
+    for r in range(1, world_size):
+        target = total * r / world_size
+        while i < tiles and run + cost[i] * 0.5 < target:      # cut at the tile boundary nearest to the target
+            run += cost[i]
+            i += 1
+        lo = cuts[-1] + (1 if tiles - cuts[-1] >= world_size - r + 1 else 0)    # leave this rank a tile ...
+        hi = max(lo, tiles - (world_size - r))                                   # ... and one for each rank behind it
+        cuts.append(min(max(i, lo), hi))
+        while i < cuts[-1]:
+            run += cost[i]
+            i += 1
+    cuts.append(tiles)
+    return [(min(a * align, w), min(b * align, w)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+class SlabBalancer:
+    """Refines a per-tile-column cost density from MEASURED slab times: after every round, the density inside each
+    rank's slab is rescaled so that the slab's total equals the time that rank measured, and the boundaries are
+    re-cut for equal totals.  A few rounds bring the slowest rank within a few percent of the mean (contiguous equal
+    slabs of the headline frame differ by 23 %).  All ranks must call update() with the same list of times."""
+
+    def __init__(self, w, world_size, tile_col_cost=None, align=8):
+        self.w, self.world, self.align = w, world_size, align
+        tiles = (w + align - 1) // align
+        self.density = [1.0] * tiles if tile_col_cost is None else [max(float(c), 1e-12) for c in tile_col_cost]
+        self.bounds = weighted_slab_bounds(self.density, w, world_size, align)
+
+    def update(self, slab_times):
+        for (a, b), t in zip(self.bounds, slab_times):
+            ta, tb = a // self.align, (b + self.align - 1) // self.align
+            tot = sum(self.density[ta:tb])
+            if tb > ta and tot > 0 and t > 0:
+                k = float(t) / tot
+                for i in range(ta, tb):
+                    self.density[i] *= k
+        self.bounds = weighted_slab_bounds(self.density, self.w, self.world, self.align)
+        return self.bounds
+
+
 class FrameGatherer:
     """Assembles per-rank slabs of shape (3, x1-x0, h) into (3,w,h) frames on rank `dst`.
 
@@ -34,69 +89,64 @@ class FrameGatherer:
     collective costs tens of microseconds however small it is, a slab of a 1080p frame renders in less, so a
     sequence of frames is assembled F at a time (fewer, larger collectives)."""
 
-    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2, batch=1):
+    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2, batch=1, bounds=None):
         import torch
         self.torch, self.dist, self.dst = torch, dist, dst
         self.w, self.h, self.batch = w, h, int(batch)
         assert self.batch >= 1
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.bounds = [slab_bounds(w, self.world, r) for r in range(self.world)]
-        widths = {b - a for a, b in self.bounds}
-        self.equal = len(widths) == 1
-        self.ws = self.bounds[self.rank][1] - self.bounds[self.rank][0]
+        self.bounds = [tuple(b) for b in bounds] if bounds is not None else [slab_bounds(w, self.world, r) for r in range(self.world)]
+        assert len(self.bounds) == self.world and self.bounds[0][0] == 0 and self.bounds[-1][1] == w
+        assert all(self.bounds[i][1] == self.bounds[i + 1][0] for i in range(self.world - 1)), "slabs must tile the width"
+        widths = [b - a for a, b in self.bounds]
+        self.equal = len(set(widths)) == 1
+        self.ws = widths[self.rank]
+        # ragged slabs (weighted boundaries, or a width that does not divide): every rank's slab lives in a buffer
+        # padded to the widest slab, so that the exchange is still ONE gather; the padding columns travel unused
+        self.ws_pad = max(widths)
         self.pending = [None] * slots
         self.frames = self.stage = None
         if self.rank == dst:
             self.frames = [torch.empty((self.batch, 3, w, h), dtype=dtype, device=device) for _ in range(slots)]
-            if self.equal:
-                self.stage = [torch.empty((self.world, self.batch, 3, self.ws, h), dtype=dtype, device=device) for _ in range(slots)]
+            self.stage = [torch.empty((self.world, self.batch, 3, self.ws_pad, h), dtype=dtype, device=device) for _ in range(slots)]
 
     def submit(self, slab, slot):
+        """slab: (batch, 3, ws_pad, h) contiguous; columns [0, ws) of it are this rank's pixels (ws_pad == ws for
+        equal slabs).  Render with plane_stride = ws_pad * h to fill it in place."""
         assert self.pending[slot] is None, "slot still in flight: call finish(slot) first"
         if self.batch == 1 and slab.dim() == 3:
             slab = slab.unsqueeze(0)
-        assert tuple(slab.shape) == (self.batch, 3, self.ws, self.h) and slab.is_contiguous()
-        dist, root = self.dist, self.rank == self.dst
-        if self.equal:
-            recv = [self.stage[slot][r] for r in range(self.world)] if root else None
-            self.pending[slot] = ("gather", dist.gather(slab, recv, dst=self.dst, async_op=True))
-            return
-        reqs = []                                       # ragged: plane-wise straight into the frame
-        for j in range(self.batch):
-            for c in range(3):
-                if root:
-                    for r, (a, b) in enumerate(self.bounds):
-                        if r == self.dst:
-                            self.frames[slot][j, c, a:b].copy_(slab[j, c])
-                        elif b > a:
-                            reqs.append(dist.irecv(self.frames[slot][j, c, a:b], src=r))
-                elif self.ws:
-                    reqs.append(dist.isend(slab[j, c], dst=self.dst))
-        self.pending[slot] = ("p2p", reqs)
+        assert tuple(slab.shape) == (self.batch, 3, self.ws_pad, self.h) and slab.is_contiguous()
+        root = self.rank == self.dst
+        recv = [self.stage[slot][r] for r in range(self.world)] if root else None
+        self.pending[slot] = self.dist.gather(slab, recv, dst=self.dst, async_op=True)
 
     def finish(self, slot):
-        kind, work = self.pending[slot]
+        work = self.pending[slot]
         self.pending[slot] = None
-        if kind == "gather":
-            work.wait()
-            if self.rank != self.dst:
-                return None
-            f = self.frames[slot]
+        work.wait()
+        if self.rank != self.dst:
+            return None
+        f = self.frames[slot]
+        if self.equal:
             f.view(self.batch, 3, self.world, self.ws, self.h).copy_(self.stage[slot].permute(1, 2, 0, 3, 4))
         else:
-            for q in work:
-                q.wait()
-            if self.rank != self.dst:
-                return None
-            f = self.frames[slot]
+            for r, (a, b) in enumerate(self.bounds):
+                if b > a:
+                    f[:, :, a:b].copy_(self.stage[slot][r][:, :, : b - a])
         return f[0] if self.batch == 1 else f
 
 
-def gather_frame(slab, w, h, dist, dst=0):
-    """Synchronous convenience wrapper: gather one frame; returns it on `dst`, None elsewhere."""
+def gather_frame(slab, w, h, dist, dst=0, bounds=None):
+    """Synchronous convenience wrapper: gather one frame from compact (3, ws, h) slabs; returns it on `dst`, None
+    elsewhere."""
     if dist.get_world_size() == 1:
         return slab
-    g = FrameGatherer(w, h, slab.dtype, slab.device, dist, dst=dst, slots=1)
+    g = FrameGatherer(w, h, slab.dtype, slab.device, dist, dst=dst, slots=1, bounds=bounds)
+    if g.ws_pad != g.ws:
+        padded = slab.new_zeros((3, g.ws_pad, h))
+        padded[:, : g.ws] = slab
+        slab = padded
     g.submit(slab.contiguous(), 0)
     return g.finish(0)
 
@@ -111,15 +161,17 @@ class SequencePipeline:
       * collectives must be few, so the uint8 slabs of `frames_per_gather` consecutive frames travel in ONE gather,
         issued on a separate stream behind events from the render streams, two exchanges in flight.
 
-    submit(launch) queues one frame: launch(u8, f32, stream) must enqueue the rendering of this rank's slab into the
-    (3, ws, h) tensors `u8` / `f32` on `stream` (a raw stream handle, or None on CPU, where it runs synchronously).
+    submit(launch) queues one frame: launch(u8, f32, stream) must enqueue the rendering of this rank's slab into
+    columns [0, ws) of the (3, ws_pad, h) tensors `u8` / `f32` (plane stride = self.plane_stride elements; ws_pad = ws
+    unless the ranks' slabs are unequal) on `stream` (a raw stream handle, or None on CPU, where it runs synchronously).
     drain() completes everything queued.  on_frames(first_index, frames, count), if given, is called on `dst` for
     every assembled batch (`frames` is (F, 3, w, h); only the first `count` are new).  Without a process group
     (dist=None) nothing is exchanged and on_frames is not called; last_slab() returns the newest slab.
 
     On a CUDA/HIP device this uses torch streams and events; on CPU (the gloo tests) everything is synchronous."""
 
-    def __init__(self, w, h, ws, device, dist=None, dst=0, streams=3, frames_per_gather=8, want_f32=True, on_frames=None):
+    def __init__(self, w, h, ws, device, dist=None, dst=0, streams=3, frames_per_gather=8, want_f32=True, on_frames=None,
+                 bounds=None):
         import torch
         self.torch, self.dist, self.dst, self.on_frames = torch, dist, dst, on_frames
         self.gpu = torch.device(device).type == "cuda"
@@ -128,9 +180,15 @@ class SequencePipeline:
         self.SLOTS = 2 if dist is not None else self.NS
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.NS)] if self.gpu else [None]
         self.comm = torch.cuda.Stream(device=device) if (self.gpu and dist is not None) else None
-        self.u8 = [torch.zeros((self.F, 3, ws, h), dtype=torch.uint8, device=device) for _ in range(self.SLOTS)]
-        self.f32 = [torch.zeros((self.F, 3, ws, h), dtype=torch.float32, device=device) for _ in range(self.SLOTS)] if want_f32 else None
-        self.gatherer = FrameGatherer(w, h, torch.uint8, device, dist, dst=dst, slots=self.SLOTS, batch=self.F) if dist is not None else None
+        self.gatherer = FrameGatherer(w, h, torch.uint8, device, dist, dst=dst, slots=self.SLOTS, batch=self.F, bounds=bounds) if dist is not None else None
+        if self.gatherer is not None:
+            assert self.gatherer.ws == ws, "ws must be this rank's slab width under `bounds`"
+        # slabs are stored padded to the widest rank's width (one gather even when the slabs are unequal): render
+        # with plane_stride = self.plane_stride
+        self.ws, self.ws_pad = ws, (self.gatherer.ws_pad if self.gatherer is not None else ws)
+        self.plane_stride = self.ws_pad * h
+        self.u8 = [torch.zeros((self.F, 3, self.ws_pad, h), dtype=torch.uint8, device=device) for _ in range(self.SLOTS)]
+        self.f32 = [torch.zeros((self.F, 3, self.ws_pad, h), dtype=torch.float32, device=device) for _ in range(self.SLOTS)] if want_f32 else None
         # per-frame views, made once: indexing a tensor costs microseconds, and a 1080p slab renders in ~100
         self.u8v = [[t[j] for j in range(self.F)] for t in self.u8]
         self.f32v = [[t[j] for j in range(self.F)] for t in self.f32] if want_f32 else None
@@ -201,6 +259,15 @@ class SequencePipeline:
 
     def last_slab(self):
         return self._last
+
+    def close(self, renderer=None):
+        """Before the torch streams go away: let the renderer's context forget their handles (it fences streams that
+        launched on it when it rebuilds what they may still read; include/mi355rt.h: rt_stream_forget)."""
+        if self.gpu:
+            self.torch.cuda.synchronize()
+            if renderer is not None:
+                for hnd in self.handles + ([self.comm.cuda_stream] if self.comm is not None else []):
+                    renderer.stream_forget(hnd)
 
 
 class _nullcontext:

@@ -85,9 +85,9 @@ class _Launch:
         if isinstance(result, _cuda.DeviceNDArray):
             host = result.copy_to_host()
             host[:, :cx, :cy] = out8[:, :, :cy]
-            result._host[...] = host
+            result._host = host
             if result._dptr is not None:
-                r.h2d(result._dptr, result._host)
+                r.h2d(result._dptr, host)
             result.version += 1
         else:
             result[:, :cx, :cy] = out8[:, :, :cy]

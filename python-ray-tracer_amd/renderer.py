@@ -45,6 +45,7 @@ class Renderer:
             raise RenderError(st, self._lib.rt_last_error(None).decode())
         self.device = int(device)
         self.w = self.h = None
+        self._pinned = {}                # host_array(): data address -> allocation
         self.generation = {"scene": 0, "camera": 0, "grid": 0}   # bumped by every set_*: caches above this class key on it
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -54,6 +55,9 @@ class Renderer:
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            for ptr in list(getattr(self, "_pinned", {}).values()):
+                self._lib.rt_host_free(self._ctx, C.c_void_p(ptr))
+            self._pinned = {}
             self._lib.rt_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -134,6 +138,43 @@ class Renderer:
         self._check(self._lib.rt_render(self._ctx, C.byref(p), int(x0), x1,
                                         out8.ctypes.data if u8 else None, out32.ctypes.data if f32 else None))
         return out8, out32
+
+    def render_into(self, amb, lamb, refl, depth, aa, out8, out32=None, *, x0=0, x1=None, flags=0, refl_pow=None, spp=0, seed=1):
+        """Synchronous render into caller-provided host arrays (C-contiguous uint8 / float32 of shape (3, x1-x0, h);
+        page-locked ones from host_array() make the copy back run at the link's rate)."""
+        x1 = (self.w or 0) if x1 is None else int(x1)
+        p = self.params(amb, lamb, refl, depth, aa, flags, refl_pow, spp, seed)
+        for a, dt in ((out8, np.uint8), (out32, np.float32)):
+            if a is not None and (a.dtype != dt or not a.flags["C_CONTIGUOUS"] or a.size != 3 * (x1 - int(x0)) * (self.h or 0)):   # (3,ws,h), or (h,ws,3) with RT_FLAG_U8_HWC
+                raise ValueError("output arrays must be C-contiguous uint8 / float32 with 3*(x1-x0)*h elements")
+        self._check(self._lib.rt_render(self._ctx, C.byref(p), int(x0), x1,
+                                        out8.ctypes.data if out8 is not None else None,
+                                        out32.ctypes.data if out32 is not None else None))
+
+    def host_array(self, shape, dtype):
+        """A page-locked (pinned) numpy array owned by the library; give it back with release_host_array()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        self._check(self._lib.rt_host_alloc(self._ctx, n, C.byref(ptr)))
+        arr = np.frombuffer((C.c_uint8 * n).from_address(ptr.value), dtype=dtype).reshape(shape)
+        self._pinned[arr.ctypes.data] = ptr.value
+        return arr
+
+    def release_host_array(self, arr):
+        ptr = self._pinned.pop(arr.ctypes.data, None)
+        if ptr and self._ctx.value:
+            self._check(self._lib.rt_host_free(self._ctx, C.c_void_p(ptr)))
+
+    def host_arrays(self, want_f32=False, pinned=True):
+        """(uint8, float32 or None) output arrays for a full frame, page-locked or plain."""
+        shape = (3, self.w, self.h)
+        mk = (lambda dt: self.host_array(shape, dt)) if pinned else (lambda dt: np.empty(shape, dt))
+        return mk(np.uint8), (mk(np.float32) if want_f32 else None)
+
+    def release_host_arrays(self, arrs):
+        for a in arrs:
+            if a is not None:
+                self.release_host_array(a)
 
     def render_device(self, params, x0, x1, d_u8=None, d_f32=None, plane_stride=None, stream=None):
         """Asynchronous render into caller-owned device memory (raw addresses, e.g. tensor.data_ptr())."""

@@ -27,6 +27,35 @@ def test_slab_bounds_partition():
         slab_bounds(64, 2, 2)
 
 
+def test_weighted_slab_bounds_and_balancer():
+    """Cost-weighted boundaries tile the width, stay tile-aligned, give every rank work, and SlabBalancer converges on
+    a synthetic machine whose slab time is the sum of hidden per-column costs plus a fixed launch cost."""
+    from python_ray_tracer_amd.distributed import weighted_slab_bounds, SlabBalancer, slab_bounds
+    rng = np.random.default_rng(3)
+    for w in (8, 37, 128, 1920, 7680):
+        tiles = (w + 7) // 8
+        for n in (1, 2, 3, 4, 8):
+            cost = rng.uniform(0.1, 5.0, tiles)
+            b = weighted_slab_bounds(cost, w, n)
+            assert len(b) == n and b[0][0] == 0 and b[-1][1] == w
+            assert all(b[i][1] == b[i + 1][0] for i in range(n - 1)) and all(a % 8 == 0 for a, _ in b if a < w)
+            if tiles >= n:
+                assert all(y > x for x, y in b), (w, n, b)
+    assert weighted_slab_bounds([1.0] * 240, 1920, 8) == [slab_bounds(1920, 8, r) for r in range(8)]
+    assert weighted_slab_bounds([0.0] * 16, 128, 4) == [slab_bounds(128, 4, r) for r in range(4)]
+    with pytest.raises(ValueError):
+        weighted_slab_bounds([1.0] * 3, 128, 2)
+    hidden = 1.0 + 4.0 * np.exp(-((np.arange(240) - 150) / 25.0) ** 2)        # a cluster of expensive columns
+    for n in (2, 4, 8):
+        bal = SlabBalancer(1920, n)
+        t = lambda bounds: [0.002 * n + hidden[a // 8:b // 8].sum() / hidden.sum() for a, b in bounds]     # noqa: E731
+        first = t(bal.bounds)
+        for _ in range(4):
+            bal.update(t(bal.bounds))
+        last = t(bal.bounds)
+        assert max(first) / np.mean(first) > 1.15 and max(last) / np.mean(last) < 1.04, (n, first, last)
+
+
 def _worker(rank, world, port, case, out_path):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -139,7 +168,8 @@ def _batch_worker(rank, world, port, case, batch, nframes, out_path):
     w, h = int(g["w"]), int(g["h"])
     x0, x1 = slab_bounds(w, world, rank)
     gat = FrameGatherer(w, h, torch.uint8, torch.device("cpu"), dist, dst=0, slots=2, batch=batch)
-    slabs = [torch.zeros((batch, 3, x1 - x0, h), dtype=torch.uint8) for _ in range(2)]
+    assert gat.ws == x1 - x0 and gat.ws_pad >= gat.ws
+    slabs = [torch.zeros((batch, 3, gat.ws_pad, h), dtype=torch.uint8) for _ in range(2)]     # padded to the widest slab
     first, got = [None, None], {}
 
     def collect(b):
@@ -156,7 +186,7 @@ def _batch_worker(rank, world, port, case, batch, nframes, out_path):
             collect(b)
         r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
                        raygen=raygen_closed_form(w, h, float(g["fov"])), x0=x0, x1=x1, want=("u8",), nthreads=2)
-        slabs[b][j].copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
+        slabs[b][j][:, : x1 - x0].copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
         if j == 0:
             first[b] = i
         if j == batch - 1 or i == nframes - 1:
@@ -172,7 +202,7 @@ def _batch_worker(rank, world, port, case, batch, nframes, out_path):
 
 @pytest.mark.parametrize("world,case,batch,nframes", [(2, "c1_128", 3, 8), (3, "odd_37x29", 2, 5)])
 def test_batched_gather(tmp_path, oracle, world, case, batch, nframes):
-    """Equal slabs (one gather per F frames) and ragged slabs (point-to-point), last batch partly filled."""
+    """Equal slabs and ragged slabs (padded to the widest): one gather per F frames either way, last batch partly filled."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "frames.npz")
     mp.spawn(_batch_worker, args=(world, _free_port(), case, batch, nframes, out), nprocs=world, join=True)
@@ -185,31 +215,36 @@ def test_batched_gather(tmp_path, oracle, world, case, batch, nframes):
         assert np.array_equal(got[f"f{i}"], ref), f"frame {i}"
 
 
-def _sequence_worker(rank, world, port, batch, nframes, drains, out_path):
+def _sequence_worker(rank, world, port, batch, nframes, drains, out_path, weighted=False):
     """SequencePipeline on CPU (gloo): the slot/batch bookkeeping bench.py relies on, with drains in the middle."""
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import torch
     import torch.distributed as dist
     from oracle import oracle as orc
-    from python_ray_tracer_amd.distributed import slab_bounds, SequencePipeline
+    from python_ray_tracer_amd.distributed import slab_bounds, weighted_slab_bounds, SequencePipeline
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     g = load_frame("c1_128")
     w, h = 128, 128
-    x0, x1 = slab_bounds(w, world, rank)
+    bounds = [slab_bounds(w, world, q) for q in range(world)]
+    if weighted:                                           # cost-weighted, unequal slabs: still one (padded) gather
+        bounds = weighted_slab_bounds([1.0 + 3.0 * (i >= 8) for i in range(16)], w, world)
+        assert len({b - a_ for a_, b in bounds}) > 1
+    x0, x1 = bounds[rank]
     got = {}
 
     def on_frames(first, frames, count):
         for j in range(count):
             got[first + j] = frames[j].numpy().copy()
     pipe = SequencePipeline(w, h, x1 - x0, torch.device("cpu"), dist, dst=0, streams=3, frames_per_gather=batch,
-                            want_f32=False, on_frames=on_frames)
+                            want_f32=False, on_frames=on_frames, bounds=bounds)
+    assert pipe.plane_stride == max(b - a_ for a_, b in bounds) * h
     for i in range(nframes):
         def launch(u8, f32, stream, i=i):
-            assert f32 is None and stream is None and tuple(u8.shape) == (3, x1 - x0, h)
+            assert f32 is None and stream is None and tuple(u8.shape) == (3, pipe.ws_pad, h)
             r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
                            raygen=raygen_closed_form(w, h, 45.0), x0=x0, x1=x1, want=("u8",), nthreads=2)
-            u8.copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
+            u8[:, : x1 - x0].copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
         pipe.submit(launch)
         if i + 1 in drains:
             pipe.drain()
@@ -223,11 +258,12 @@ def _sequence_worker(rank, world, port, batch, nframes, drains, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch,nframes,drains", [(3, 10, (4,)), (1, 4, ()), (4, 9, (2, 8))])
-def test_sequence_pipeline(tmp_path, oracle, batch, nframes, drains):
+@pytest.mark.parametrize("world,batch,nframes,drains,weighted", [(2, 3, 10, (4,), False), (2, 1, 4, (), False), (2, 4, 9, (2, 8), False),
+                                                                 (3, 2, 7, (3,), True)])
+def test_sequence_pipeline(tmp_path, oracle, world, batch, nframes, drains, weighted):
     import torch.multiprocessing as mp
     out = str(tmp_path / "frames.npz")
-    mp.spawn(_sequence_worker, args=(2, _free_port(), batch, nframes, drains, out), nprocs=2, join=True)
+    mp.spawn(_sequence_worker, args=(world, _free_port(), batch, nframes, drains, out, weighted), nprocs=world, join=True)
     got = np.load(out)
     g = load_frame("c1_128")
     refs = [oracle.render(128, 128, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, d, False,

@@ -125,6 +125,66 @@ def test_column_slabs_assemble_bit_identical(renderer, nranks):
     assert np.array_equal(np.concatenate([p[1] for p in parts], axis=1), full32)
 
 
+def test_c2_eight_slabs_in_place_full_frame(renderer):
+    """BASELINE config 3's geometry on one GPU: the 1920x1080 frame as eight 240-column slabs, each rendered IN
+    PLACE into one device frame (base = column x0, plane_stride = w*h), must be the reference frame; so must the
+    weighted (unequal) slab boundaries of distributed.weighted_slab_bounds."""
+    import hashlib
+    from python_ray_tracer_amd.distributed import slab_bounds, weighted_slab_bounds
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+    d8, d32 = renderer.malloc(3 * w * h), renderer.malloc(12 * w * h)
+    try:
+        cost = np.linspace(1.0, 3.0, (w + 7) // 8)            # any positive weights: the frame must not depend on them
+        for bounds in ([slab_bounds(w, 8, r) for r in range(8)], weighted_slab_bounds(cost, w, 8), weighted_slab_bounds(cost, w, 3)):
+            assert bounds[0][0] == 0 and bounds[-1][1] == w
+            renderer.h2d(d8, np.zeros((3, w, h), np.uint8)); renderer.h2d(d32, np.zeros((3, w, h), np.float32))
+            for (a, b) in bounds:
+                renderer.render_device(p, a, b, d8 + a * h, d32 + 4 * a * h, w * h)
+            renderer.sync()
+            u8, f32 = np.empty((3, w, h), np.uint8), np.empty((3, w, h), np.float32)
+            renderer.d2h(u8, d8); renderer.d2h(f32, d32)
+            assert np.array_equal(u8, g["frame_u8"]), f"{(u8 != g['frame_u8']).any(axis=0).sum()} pixels differ"
+            assert hashlib.sha256(f32.tobytes()).hexdigest() == str(g["sha256_rgb32"])
+    finally:
+        renderer.free(d8); renderer.free(d32)
+
+
+def test_host_path_chunked_and_pinned(renderer):
+    """rt_render of a large frame runs as a pipeline of column chunks (render | copy to the host): same bytes as the
+    goldens, into pageable and into page-locked arrays, uint8 alone and with the float32 buffer."""
+    import hashlib
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    for pinned in (False, True):
+        for want32 in (False, True):
+            bufs = renderer.host_arrays(want32, pinned=pinned)
+            try:
+                for rep in range(3):                         # measuring, measuring, settled dispatch order
+                    bufs[0][...] = 0
+                    renderer.render_into(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, *bufs, refl_pow=g["refl_pow"])
+                    assert np.array_equal(bufs[0], g["frame_u8"])
+                    if want32:
+                        assert hashlib.sha256(bufs[1].tobytes()).hexdigest() == str(g["sha256_rgb32"])
+            finally:
+                renderer.release_host_arrays(bufs)
+    # an unaligned slab of it, and the 9-tap mode across chunk edges
+    part8 = np.empty((3, 1203, h), np.uint8)
+    renderer.render_into(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, part8, x0=301, x1=1504, refl_pow=g["refl_pow"])
+    assert np.array_equal(part8, g["frame_u8"][:, 301:1504])
+    aa_chunked = np.empty((3, w, h), np.uint8)
+    renderer.render_into(0.0, 0.6, 0.3, 1, 1, aa_chunked)
+    d8 = renderer.malloc(3 * w * h)
+    try:
+        renderer.render_device(renderer.params(0.0, 0.6, 0.3, 1, 1), 0, w, d8, None, w * h)
+        renderer.sync()
+        one = np.empty((3, w, h), np.uint8); renderer.d2h(one, d8)
+    finally:
+        renderer.free(d8)
+    assert np.array_equal(aa_chunked, one)
+
+
 def test_unaligned_slab(renderer):
     g = load_frame("odd_37x29")
     w, h, _ = _setup(renderer, g)
@@ -560,3 +620,16 @@ def test_c_abi_example_without_python(tmp_path, renderer):
     ref, _ = renderer.render(0.0, 0.6, 0.3, 2, 1, u8=True, f32=False, flags=L.RT_FLAG_U8_HWC | L.RT_FLAG_U8_RGB,
                              refl_pow=[math.pow(0.3, i + 1) for i in range(2)])
     assert np.array_equal(img, ref)
+
+
+def test_renderer_example_writes_png(tmp_path):
+    """examples/render_png.py: Renderer API, device-side (h,w,3) image into page-locked memory, PNG on disk."""
+    import subprocess, sys
+    from conftest import REPO
+    out = str(tmp_path / "r.png")
+    log = subprocess.check_output([sys.executable, os.path.join(REPO, "examples", "render_png.py"), "--size", "160x96", "--depth", "2",
+                                   "--aa", "--frames", "3", "--out", out], text=True)
+    assert "wrote" in log
+    from PIL import Image
+    im = np.asarray(Image.open(out))
+    assert im.shape == (96, 160, 3) and im.any()

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box session: tests, the driver's bench command, the default bench, and whatever experiments are listed.
+# Usage (via gpurun): bash tools/gpu_session.sh <tag> [steps...]   steps: tests bench20 bench sweep4 sweep5 prof_c2 prof_c2s1 prof_c4 prof_c5 prof_c5spp4 balance hostpath
+set -o pipefail
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+for step in "$@"; do
+  echo "== $step $(date +%T)"
+  case $step in
+    tests)    timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; rc=$?; tail -5 $OUT/tests.log; [ $rc -ne 0 ] && exit $rc ;;
+    bench20)  timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench20.json'));print({k:d[k] for k in ('value','ms_per_step','frame_ms_median','frame_ms_min','launch_ms_median','preheat_ms','host_path_ms')}, d['roofline']['serial'], d.get('cpu_baseline'))" ;;
+    bench)    timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench.json'));print({k:d[k] for k in ('value','ms_per_step','frame_ms_median','frame_ms_min','launch_ms_median','rays_traced')})" ;;
+    bench_noev) timeout -k 10 300 python bench.py --no-cpu-baseline --no-step-events --no-serial --no-host-path > $OUT/bench_noev.json 2> $OUT/bench_noev.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench_noev.json'));print(d['ms_per_step'])" ;;
+    sweep4)   timeout -k 10 300 python tools/depth_sweep.py --workload c4_3840x2160_s64_d5 > $OUT/sweep4.log 2>&1 || exit 1; cat $OUT/sweep4.log ;;
+    sweep5)   timeout -k 10 400 python tools/depth_sweep.py --workload c5_7680x4320_s256_d8 --launches 3 > $OUT/sweep5.log 2>&1 || exit 1; cat $OUT/sweep5.log ;;
+    prof_c2)  timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c2 --stamp || exit 1 ;;
+    prof_c2s1) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c2_serial --streams 1 --no-pmc || exit 1 ;;
+    prof_c4)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 200 --trace-warmup 10 --pmc-steps 6 --sets sq1,sq2,sq3,sq4 || exit 1 ;;
+    prof_c5)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 30 --trace-warmup 3 --pmc-steps 3 --sets sq1,sq2,sq3,sq4 || exit 1 ;;
+    prof_c5spp4) timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --pmc-steps 2 --sets sq1,sq3 || exit 1 ;;
+    trace_c4) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 200 --trace-warmup 10 --no-pmc || exit 1 ;;
+    trace_c5) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 30 --trace-warmup 3 --no-pmc || exit 1 ;;
+    trace_c5spp4) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --no-pmc || exit 1 ;;
+    balance)  timeout -k 10 400 python tools/slab_balance.py > $OUT/balance.log 2>&1 || exit 1; cat $OUT/balance.log ;;
+    aa)       timeout -k 10 200 python examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/aa.log 2>&1 || exit 1; cat $OUT/aa.log ;;
+    fuzz)     timeout -k 10 400 python tools/fuzz_parity.py --seconds 240 --seed ${FUZZ_SEED:-201} > $OUT/fuzz.log 2>&1; rc=$?; tail -3 $OUT/fuzz.log; [ $rc -ne 0 ] && exit $rc ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+done
+echo "== done $(date +%T)"
