@@ -206,7 +206,7 @@ def main():
     # step's kernel was launched on (torch.cuda.Event on a stream object records on THAT stream, not on torch's
     # current one).  Launches of one stream run back to back, so the gap between consecutive events of a stream is
     # the duration of one launch as rocprofv3's kernel trace sees it; the gaps between consecutive completions over
-    # all streams are the frame periods.  NS launches are in flight at a time.
+    # all streams give the frame periods (over windows of NS completions).  NS launches are in flight at a time.
     step_events = not a.no_step_events
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
@@ -238,8 +238,10 @@ def main():
             per_launch.append(last[s_].elapsed_time(evs[i]))
             last[s_] = evs[i]
             done.append(ev0[0].elapsed_time(evs[i]))     # completion time of step i on a common clock
+        # NS launches are in flight together and complete in clumps, so the period of a frame is taken over a window
+        # of NS consecutive completions: (t[i] - t[i - NS]) / NS
         done.sort()
-        periods = [b - c for b, c in zip(done[1:], done[:-1])]
+        periods = [(done[i] - done[i - NS]) / NS for i in range(NS, len(done))]
     if not use_gather:
         frame = pipe.last_slab()[:, :ws]
 

@@ -52,7 +52,9 @@ typedef enum rt_status {
 #define RT_AA_NONE 0      /* aliasing=False                                        kernels.py:26 only */
 #define RT_AA_REFERENCE 1 /* aliasing=True: the reference's 3x3 half-pixel taps incl. its G/B
                              accumulation order (kernels.py:29-65) on 1<=x<=w-2, 1<=y<=h-2; the
-                             frame border, where the reference indexes out of bounds, gets one tap */
+                             frame border, where the reference indexes out of bounds, gets one tap.
+                             With the closed-form grid (rt_set_raygen) neighbouring pixels' shared taps are
+                             traced once: see RT_FLAG_AA_PER_PIXEL */
 #define RT_AA_STOCHASTIC 2 /* build-defined (the reference has no such mode; README "anti aliasing" to-do):
                              rt_params.spp samples per pixel at P + u*dy*y^ + v*dz*z^ with (u,v) in [-1/2,1/2)^2
                              from a counter hash of (x, y, sample, seed) — rt_device.h:jitter(); plain mean of the
@@ -76,6 +78,9 @@ typedef enum rt_status {
                                 order is kept and measuring stops until an rt_set_* call or another
                                 range/depth/mode/stream starts it again */
 
+#define RT_FLAG_AA_PER_PIXEL 32 /* RT_AA_REFERENCE: trace all nine taps of every pixel (what the reference does, kernels.py:29-65)
+                                  instead of tracing each half-pixel lattice sample once and summing nine per pixel — the
+                                  default on the closed-form grid, same bytes, 4 instead of 9 samples per pixel */
 #define RT_FLAG_COUNT_RAYS 16 /* run the counting instantiation of the kernel (slower: registers instead of LDS-parked
                                 state): adds this launch's ray counts to the context's rt_stats.  Same pixels. */
 

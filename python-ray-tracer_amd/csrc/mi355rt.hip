@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -27,13 +28,16 @@ struct Buf {
 }  // namespace
 
 #define RT_FEEDBACK_SLOTS 8
-#define RT_RENDER_CHUNKS 4
+#define RT_RENDER_CHUNKS 8   /* upper bound; the pipeline uses ctx->render_chunks of them */
 
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, copy_stream = nullptr;   // rt_render's chunk pipeline (created on first use)
     hipEvent_t chunk_ev[RT_RENDER_CHUNKS] = {};
+    hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
+    int chunk_mode = 0;
+    int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
     int S = 0, P = 0, L = 0;
@@ -72,6 +76,7 @@ struct rt_ctx {
     unsigned long long fb_stamp = 0;
     rt_stats stats = {};              // host-side launch counters (the ray counters live in `counts`)
     Buf counts;                       // 4 x uint64 on the device: ray counters of RT_FLAG_COUNT_RAYS launches
+    std::vector<std::pair<hipStream_t, Buf>> lattice;   // per launching stream: float64 lattice samples (RT_AA_REFERENCE)
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
     unsigned long long scene_epoch = 1;   // bumped by rt_set_scene only
     // The float32 cull tables (rt::tables_kernel) of the last few (scene, camera position, floor) combinations.
@@ -140,6 +145,13 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     }
     if (x0 < 0 || x1 > ctx->w || x0 >= x1) return fail(ctx, RT_ERR_BAD_ARG, "column range must satisfy 0 <= x0 < x1 <= w");
     return RT_OK;
+}
+
+const void *lattice_variant(bool park, int wpw, bool count = false)     // the plain kernel over the half-pixel lattice (RT_AA_REFERENCE)
+{
+    if (count) return (const void *)rt::render_kernel<false, false, 4, true, true>;
+    if (wpw == 2) return park ? (const void *)rt::render_kernel<false, true, 2, false, true> : (const void *)rt::render_kernel<false, false, 2, false, true>;
+    return park ? (const void *)rt::render_kernel<false, true, 4, false, true> : (const void *)rt::render_kernel<false, false, 4, false, true>;
 }
 
 const void *kernel_variant(bool aa, bool park, int wpw, bool count = false)
@@ -213,6 +225,26 @@ int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const 
     return RT_OK;
 }
 
+int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream);
+
+// The lattice buffer of a stream (RT_AA_REFERENCE with the closed-form grid renders the half-pixel lattice once into
+// float64 samples, then sums nine of them per pixel): one buffer per launching stream, so that frames in flight on
+// different streams keep their samples apart.
+int lattice_buffer(rt_ctx *ctx, hipStream_t stream, size_t bytes, double **out)
+{
+    for (auto &e : ctx->lattice)
+        if (e.first == stream) {
+            if (e.second.cap < bytes) RT_HIP(ctx, hipStreamSynchronize(stream));
+            int rc = ensure(ctx, e.second, bytes);
+            *out = (double *)e.second.p;
+            return rc;
+        }
+    ctx->lattice.emplace_back(stream, Buf{});
+    int rc = ensure(ctx, ctx->lattice.back().second, bytes);
+    *out = (double *)ctx->lattice.back().second.p;
+    return rc;
+}
+
 int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_f32, int64_t plane_stride,
            hipStream_t stream)
 {
@@ -250,6 +282,40 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         int rc = acquire_tables(ctx, k, stream, &k.ftab);
         if (rc != RT_OK) return rc;
     }
+    // RT_AA_REFERENCE on the closed-form grid: the reference's nine taps of a pixel are the 3x3 neighbourhood of the
+    // pixel's centre on the (2w-1) x (2h-1) half-pixel lattice — the tap between two pixels is 0.5 Pa + 0.5 Pb, bit
+    // for bit the same from either side (IEEE addition commutes), and with a separable grid both diagonals of a cell
+    // cross in the same point.  So every lattice sample is traced ONCE (4 per pixel instead of 9) by the plain kernel
+    // over the lattice "frame", stored as float64 (R,G,B), and a second small kernel sums each pixel's nine samples in
+    // the reference's order (kernels.py:53-65, including its G/B swap).  Explicit pixel_loc grids are not separable
+    // in general and keep the nine-taps-per-pixel kernel.
+    const long long LW = 2ll * ctx->w - 1, LH = 2ll * ctx->h - 1;
+    if (k.aa == RT_AA_REFERENCE && !ctx->explicit_grid && LW * LH < (1ll << 31) && !(p->flags & RT_FLAG_AA_PER_PIXEL)) {
+        const int li0 = std::max(0, 2 * x0 - 1), li1 = (int)std::min(LW - 1, 2ll * x1 - 1);       // lattice columns, inclusive
+        double *lat = nullptr;
+        int rc = lattice_buffer(ctx, stream, (size_t)(li1 - li0 + 1) * (size_t)LH * 3 * sizeof(double), &lat);
+        if (rc != RT_OK) return rc;
+        rt::KParams kl = k;
+        kl.aa = 0; kl.lattice = 1; kl.out_u8 = nullptr; kl.out_f32 = nullptr; kl.out_f64 = lat; kl.tile_cycles = nullptr;
+        kl.w = (int)LW; kl.h = (int)LH; kl.x0 = li0; kl.x1 = li1 + 1; kl.plane_stride = 0;
+        kl.tiles_y = ((int)LH + rt::TILE - 1) / rt::TILE;
+        kl.ntiles = ((li1 + 1 - li0 + rt::TILE - 1) / rt::TILE) * kl.tiles_y;
+        rc = dispatch(ctx, p, kl, true, stream);
+        if (rc != RT_OK) return rc;
+        k.out_f64 = lat; k.lat_x0 = li0; k.lat_h = (int)LH;
+        const long long npx = (long long)(x1 - x0) * ctx->h;
+        hipLaunchKernelGGL(rt::aa_resolve_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, k);
+        RT_HIP(ctx, hipGetLastError());
+        return RT_OK;
+    }
+    return dispatch(ctx, p, k, false, stream);
+}
+
+// Chooses the kernel instantiation and the dispatch order for one launch of the render kernel over the tiles k
+// describes, and launches it.
+int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream)
+{
+    const int x0 = k.x0, x1 = k.x1;
     // Workgroup size: 2 tiles (wavefronts) for scenes whose LDS image (records + cull tables) is small, 4 otherwise
     // (every workgroup stages its own copy; rt_device.h has the measurements).
     // Kernel variant: state parked in LDS (7 waves/SIMD, no scratch) while at least 24 wavefronts per CU still
@@ -262,12 +328,15 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
     const bool park = !count && lds_park * (24 / wpw) <= 160 * 1024;
     const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt);
-    const void *fn = kernel_variant(aa, park, wpw, count);
+    const void *fn = lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count);
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int v = 0; v < 2; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 4; ++v)
+            RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(v & 1, (v & 2) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
     }
     if (count) {
@@ -284,7 +353,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
     rt_ctx::Feedback::Key key;
-    key.valid = true; key.x0 = x0; key.x1 = x1; key.h = ctx->h; key.aa = k.aa; key.depth = k.depth;
+    key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
     key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw;
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
@@ -400,6 +469,8 @@ int rt_create(rt_ctx **out, int device)
     rt_ctx *ctx = new (std::nothrow) rt_ctx;
     if (!ctx) return fail(nullptr, RT_ERR_ALLOC, "out of host memory");
     ctx->device = device;
+    if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
+    if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (s = hipEventCreate(&ctx->ev0)) != hipSuccess || (s = hipEventCreate(&ctx->ev1)) != hipSuccess) {
@@ -418,6 +489,7 @@ int rt_destroy(rt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->counts})
         if (b->p) (void)hipFree(b->p);
+    for (auto &e : ctx->lattice) if (e.second.p) (void)hipFree(e.second.p);
     for (auto &f : ctx->fbs) {
         for (Buf *b : {&f.hist, &f.slot, &f.order}) if (b->p) (void)hipFree(b->p);
         for (auto &r : f.readers) (void)hipEventDestroy(r.second);
@@ -433,6 +505,7 @@ int rt_destroy(rt_ctx *ctx)
     for (hipEvent_t e : ctx->spare_events) (void)hipEventDestroy(e);
     for (hipStream_t st : {ctx->stream2, ctx->copy_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipEvent_t e : ctx->chunk_ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : ctx->chunk_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -635,7 +708,8 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
     // event) while the following chunks still render: the copy of a 1080p frame costs about as much as rendering it,
     // and this hides all of it but the last chunk's.  (main.py:41-51: launch, then copy_to_host.)
     const int tiles = (x1 - x0 + rt::TILE - 1) / rt::TILE;
-    if (hwc || npx < (1u << 19) || tiles < 4 * RT_RENDER_CHUNKS) {
+    const int NCH = ctx->render_chunks;
+    if (hwc || NCH < 2 || npx < (1u << 19) || tiles < 4 * NCH) {
         rc = launch(ctx, params, x0, x1, out_u8 ? ctx->u8.p : nullptr, out_f32 ? ctx->f32.p : nullptr,
                     hwc ? (int64_t)(x1 - x0) : (int64_t)npx, ctx->stream);
         if (rc != RT_OK) return rc;
@@ -644,28 +718,45 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return RT_OK;
     }
+    const bool instream = ctx->chunk_mode == 1;                 // MI355RT_CHUNK_MODE=1: every chunk on its own stream, its copy behind it
     if (!ctx->copy_stream) {
         RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         for (auto &e : ctx->chunk_ev) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int lo = 0, hi = 0;
+        RT_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent (numerically largest)
+        for (int c = 0; c < RT_RENDER_CHUNKS; ++c)
+            RT_HIP(ctx, hipStreamCreateWithPriority(&ctx->chunk_stream[c], hipStreamNonBlocking, std::min(lo, hi + c)));
     }
     int cx[RT_RENDER_CHUNKS + 1];
-    for (int c = 0; c <= RT_RENDER_CHUNKS; ++c) cx[c] = std::min(x1, x0 + (int)((long long)tiles * c / RT_RENDER_CHUNKS) * rt::TILE);
-    for (int c = 0; c < RT_RENDER_CHUNKS; ++c) {
-        hipStream_t s = (c & 1) ? ctx->stream2 : ctx->stream;
-        const size_t off = (size_t)(cx[c] - x0) * ctx->h;
+    // the first and the last chunk are half as wide as the others: the copies start sooner, and the one copy that
+    // nothing overlaps (the last chunk's) is short
+    for (int c = 0; c <= NCH; ++c) {
+        const int num = (c == 0) ? 0 : (c == NCH ? 2 * (NCH - 1) : 2 * c - 1);          // of 2 (NCH - 1) half-units
+        cx[c] = std::min(x1, x0 + (int)((long long)tiles * num / (2 * (NCH - 1))) * rt::TILE);
+    }
+    for (int c = 0; c < NCH; ++c) {
+        hipStream_t s = instream ? ctx->chunk_stream[c] : ((c & 1) ? ctx->stream2 : ctx->stream);
+        const size_t off = (size_t)(cx[c] - x0) * ctx->h, n = (size_t)(cx[c + 1] - cx[c]) * ctx->h;
         rc = launch(ctx, params, cx[c], cx[c + 1], out_u8 ? (uint8_t *)ctx->u8.p + off : nullptr,
                     out_f32 ? (float *)ctx->f32.p + off : nullptr, (int64_t)npx, s);
         if (rc != RT_OK) return rc;
-        RT_HIP(ctx, hipEventRecord(ctx->chunk_ev[c], s));
+        if (instream) {
+            if (out_u8) RT_HIP(ctx, hipMemcpy2DAsync(out_u8 + off, npx, (uint8_t *)ctx->u8.p + off, npx, n, 3, hipMemcpyDeviceToHost, s));
+            if (out_f32) RT_HIP(ctx, hipMemcpy2DAsync(out_f32 + off, npx * sizeof(float), (float *)ctx->f32.p + off, npx * sizeof(float),
+                                                      n * sizeof(float), 3, hipMemcpyDeviceToHost, s));
+        } else RT_HIP(ctx, hipEventRecord(ctx->chunk_ev[c], s));
     }
-    for (int c = 0; c < RT_RENDER_CHUNKS; ++c) {
+    if (instream) {
+        for (int c = 0; c < NCH; ++c) RT_HIP(ctx, hipStreamSynchronize(ctx->chunk_stream[c]));
+        return RT_OK;
+    }
+    for (int c = 0; c < NCH; ++c) {                             // a chunk's three planes = one 2-D copy (3 rows, pitch = plane)
         const size_t off = (size_t)(cx[c] - x0) * ctx->h, n = (size_t)(cx[c + 1] - cx[c]) * ctx->h;
         RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_ev[c], 0));
-        for (int pl = 0; pl < 3; ++pl) {
-            if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8 + pl * npx + off, (uint8_t *)ctx->u8.p + pl * npx + off, n, hipMemcpyDeviceToHost, ctx->copy_stream));
-            if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32 + pl * npx + off, (float *)ctx->f32.p + pl * npx + off, n * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
+        if (out_u8) RT_HIP(ctx, hipMemcpy2DAsync(out_u8 + off, npx, (uint8_t *)ctx->u8.p + off, npx, n, 3, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (out_f32) RT_HIP(ctx, hipMemcpy2DAsync(out_f32 + off, npx * sizeof(float), (float *)ctx->f32.p + off, npx * sizeof(float),
+                                                  n * sizeof(float), 3, hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     RT_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return RT_OK;
@@ -753,6 +844,10 @@ int rt_stream_create(rt_ctx *ctx, void **stream)
 static int forget_stream(rt_ctx *ctx, hipStream_t stream)
 {
     RT_HIP(ctx, hipStreamSynchronize(stream));
+    for (size_t i = 0; i < ctx->lattice.size();) {
+        if (ctx->lattice[i].first == stream) { if (ctx->lattice[i].second.p) (void)hipFree(ctx->lattice[i].second.p); ctx->lattice.erase(ctx->lattice.begin() + (long)i); }
+        else ++i;
+    }
     for (auto &f : ctx->fbs) {
         for (size_t i = 0; i < f.readers.size();) {
             if (f.readers[i].first == stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }

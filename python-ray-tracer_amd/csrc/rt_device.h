@@ -75,6 +75,9 @@ struct KParams {
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from the previous launch's costs
     const float *ftab;         // the float32 cull tables of this scene / camera / depth, built once by tables_kernel
     unsigned long long *ray_counts;   // counting instantiation only (RT_FLAG_COUNT_RAYS): {closest, shadow issued, shadow skipped, hits}
+    double *out_f64;           // lattice instantiation: float64 (R,G,B) per lattice sample, [column - x0][row][3]; aa_resolve_kernel reads it
+    int lattice;               // 1: the "frame" is the (2w-1) x (2h-1) half-pixel lattice of the pixel grid (w, h, x0, x1 are lattice units)
+    int lat_x0, lat_h;         // aa_resolve_kernel: first lattice column in out_f64, lattice rows
     long long plane_stride;    // elements between colour planes of the output
     int w, h, x0, x1;
     int S, P, L, depth;
@@ -741,6 +744,17 @@ __device__ __forceinline__ V3 pixel_P(const KParams &p, int x, int y)
     return V3{p.px, (double)x * p.dy + p.y0, (double)y * p.dz + p.z0};        // scene/camera.py:18-26
 }
 
+// Lattice point (i, j) of the half-pixel lattice of the closed-form grid: even indices are pixel centres, odd ones
+// the reference's midpoints 0.5 Pa + 0.5 Pb of the two neighbouring centres (kernels.py:43-50: c1*a + c2*b, two
+// products and one sum per component; either operand order gives the same bits).  The first component is
+// 0.5 px + 0.5 px = px exactly.
+__device__ __forceinline__ V3 lattice_P(const KParams &p, int i, int j)
+{
+    const double ya = (double)(i >> 1) * p.dy + p.y0, yb = (double)((i + 1) >> 1) * p.dy + p.y0;
+    const double za = (double)(j >> 1) * p.dz + p.z0, zb = (double)((j + 1) >> 1) * p.dz + p.z0;
+    return V3{p.px, (i & 1) ? 0.5 * ya + 0.5 * yb : ya, (j & 1) ? 0.5 * za + 0.5 * zb : za};
+}
+
 __device__ __forceinline__ V3 primary_dir(const KParams &p, const V3 &P)
 {
     const V3 v{p.cam_R[0] * P.x + p.cam_R[1] * P.y + p.cam_R[2] * P.z,       // kernels.py:22, common.py:40-49
@@ -769,6 +783,29 @@ __device__ __forceinline__ uint8_t clip_color(double c)
     if (c >= 255.5) return 255;
     const int i = (int)__builtin_rint(c);
     return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+// kernels.py:69-73: clip and store one pixel; off = (x - x0) h + y.
+__device__ __forceinline__ void store_pixel(const KParams &p, long long off, double R, double G, double B)
+{
+    if (p.out_u8) {                                                           // common.py:60-63
+        const uint8_t r8 = clip_color(R), g8 = clip_color(G), b8 = clip_color(B);
+        const uint8_t c1 = p.u8_rgb ? g8 : b8, c2 = p.u8_rgb ? b8 : g8;
+        if (p.u8_hwc) {                                                       // image layout: row y, column x, 3 bytes
+            const long long xr = off / p.h, yy = off - xr * p.h;
+            uint8_t *px = p.out_u8 + (yy * p.plane_stride + xr) * 3;
+            px[0] = r8; px[1] = c1; px[2] = c2;
+        } else {
+            p.out_u8[off] = r8;
+            p.out_u8[p.plane_stride + off] = c1;
+            p.out_u8[2 * p.plane_stride + off] = c2;
+        }
+    }
+    if (p.out_f32) {
+        p.out_f32[off] = (float)R;
+        p.out_f32[p.plane_stride + off] = (float)G;
+        p.out_f32[2 * p.plane_stride + off] = (float)B;
+    }
 }
 
 // LDS image: [float64 records][per-thread slots 6|9 x 256 doubles][256 int32 pixel offsets][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
@@ -849,7 +886,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
-template <bool AA, bool PARK, int WPW, bool COUNT = false>
+template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false>
 #ifndef RT_W_PARK
 #define RT_W_PARK 7
 #endif
@@ -894,7 +931,9 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
     const int x = p.x0 + tx * TILE + (lane >> 3);
     const int y = ty * TILE + (lane & 7);
-    const bool inb = (x < p.x1) && (y < p.h);
+    bool inb = (x < p.x1) && (y < p.h);
+    // LAT: of the lattice, only pixel centres (even, even) and the points inside the outermost centres are ever summed
+    if constexpr (LAT) inb = inb && ((((x | y) & 1) == 0) || (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2));
     const int xc = inb ? x : p.x0, yc = inb ? y : 0;                          // keep addresses valid for idle lanes
     // PARK: the pixel's output offset waits in LDS instead of staying live (or being spilled to scratch)
     // across the whole trace; -1 marks lanes outside the frame.
@@ -906,7 +945,7 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
     RayCount<COUNT> cnt;
     double R, G, B;
     if constexpr (!AA) {
-        const V3 c = sample<PARK, WG_THREADS, COUNT>(lds, p, inb, o, primary_dir(p, pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
+        const V3 c = sample<PARK, WG_THREADS, COUNT>(lds, p, inb, o, primary_dir(p, LAT ? lattice_P(p, xc, yc) : pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
         R = c.x; G = c.y; B = c.z;
     } else {
         // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
@@ -947,24 +986,10 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
     long long off;
     if constexpr (PARK) off = *offp; else off = inb ? (long long)(x - p.x0) * p.h + y : -1ll;   // (int32 -1 sign-extends)
     if (off >= 0) {
-        if (p.out_u8) {                                                       // kernels.py:69-73, common.py:60-63
-            const uint8_t r8 = clip_color(R), g8 = clip_color(G), b8 = clip_color(B);
-            const uint8_t c1 = p.u8_rgb ? g8 : b8, c2 = p.u8_rgb ? b8 : g8;
-            if (p.u8_hwc) {                                                   // image layout: row y, column x, 3 bytes
-                const long long xr = off / p.h, yy = off - xr * p.h;
-                uint8_t *px = p.out_u8 + (yy * p.plane_stride + xr) * 3;
-                px[0] = r8; px[1] = c1; px[2] = c2;
-            } else {
-                p.out_u8[off] = r8;
-                p.out_u8[p.plane_stride + off] = c1;
-                p.out_u8[2 * p.plane_stride + off] = c2;
-            }
-        }
-        if (p.out_f32) {
-            p.out_f32[off] = (float)R;
-            p.out_f32[p.plane_stride + off] = (float)G;
-            p.out_f32[2 * p.plane_stride + off] = (float)B;
-        }
+        if constexpr (LAT) {                                                  // one float64 (R,G,B) per lattice sample
+            double *q = p.out_f64 + off * 3;
+            q[0] = R; q[1] = G; q[2] = B;
+        } else store_pixel(p, off, R, G, B);
     }
     if constexpr (COUNT) {                                                    // rt_get_stats: one atomic per wave and counter
         unsigned v[4] = {cnt.n_closest, cnt.n_issued, cnt.n_skipped, cnt.n_hit};
@@ -989,6 +1014,30 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
             }
         }
     }
+}
+
+// RT_AA_REFERENCE, second half (kernels.py:29-65): pixel (x,y) sums the lattice samples around its centre (2x, 2y) in the
+// reference's order — centre, left, right, top (y+1), bottom (y-1), top-left, top-right, bottom-left, bottom-right,
+// with G += B_s and B += G_s — and divides by 9; frame-border pixels keep their centre sample.  p describes the PIXEL
+// frame (w, h, x0, x1, outputs); p.out_f64 / lat_x0 / lat_h the lattice samples.  One thread per pixel, y fastest.
+__global__ __launch_bounds__(256) void aa_resolve_kernel(const KParams p)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)(p.x1 - p.x0) * p.h) return;
+    const int xr = (int)(idx / p.h), y = (int)(idx - (long long)xr * p.h), x = p.x0 + xr;
+    const double *c = p.out_f64 + ((size_t)(2 * x - p.lat_x0) * p.lat_h + 2 * y) * 3;
+    double R = c[0], G = c[1], B = c[2];
+    if (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2) {
+        constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;                      // (dx,dy)+1, 2 bits each, in the order of kernels.py:53
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
+            const double *s = c + ((long long)ddx * p.lat_h + ddy) * 3;
+            R += s[0]; G += s[2]; B += s[1];                                  // :58-60
+        }
+        R = R / 9; G = G / 9; B = B / 9;                                      // :63-65
+    }
+    store_pixel(p, idx, R, G, B);
 }
 
 // Builds the next launch's dispatch order from what this launch recorded: tile blocks (4 tiles = one workgroup)

@@ -113,6 +113,58 @@ def test_explicit_pixel_loc_aa(renderer):
     assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, g["u8"])
 
 
+@pytest.mark.parametrize("case", ["aa_48_d2", "aa_40x24_d1"])
+def test_aa_lattice_and_per_pixel_paths_agree_with_golden(renderer, case):
+    """RT_AA_REFERENCE traces every half-pixel lattice sample once and sums nine per pixel (default on the closed-form
+    grid); RT_FLAG_AA_PER_PIXEL traces the reference's nine taps per pixel.  Both must be the reference's bytes."""
+    from python_ray_tracer_amd import _lib as L
+    g = load_frame(case)
+    _setup(renderer, g)
+    co = g["coords"]
+    for flags in (0, L.RT_FLAG_AA_PER_PIXEL):
+        u8, f32 = _render(renderer, g, flags=flags)
+        assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, g["u8"]), flags
+        assert np.array_equal(f32[:, co[:, 0], co[:, 1]].T, g["rgb64"].astype(np.float32)), flags
+    a8, a32 = _render(renderer, g)
+    b8, b32 = _render(renderer, g, flags=L.RT_FLAG_AA_PER_PIXEL)
+    assert np.array_equal(a8, b8) and np.array_equal(a32, b32)          # incl. the frame border (one tap)
+
+
+@pytest.mark.parametrize("w,h", [(3, 3), (2, 5), (1, 1), (9, 4), (67, 35), (130, 77)])
+def test_aa_lattice_odd_sizes_vs_oracle(renderer, oracle, w, h):
+    """Frame sizes around the tile size and below it (no interior pixels at all for w or h < 3), slabs that start
+    and end on odd columns, and frames of a sequence in flight on several streams (one lattice buffer per stream)."""
+    from python_ray_tracer_amd.scene import Camera
+    g = load_frame("default_128_d3")
+    cam = Camera((w, h), [-2, 0.1, 2.0], [3, -28, 4], fov=50.0)
+    rg = cam.raygen()
+    renderer.set_scene(g["spheres"], g["lights"], g["planes"]); renderer.set_camera(cam.position, cam.rotation); renderer.set_raygen(w, h, *rg)
+    ref = oracle.render(w, h, cam.position, cam.rotation, g["spheres"], g["lights"], g["planes"], 0.05, 0.6, 0.4, 2, True, raygen=rg, want=("u8", "f32"))
+    u8, f32 = renderer.render(0.05, 0.6, 0.4, 2, 1, u8=True, f32=True)
+    assert np.array_equal(u8, ref["u8"]) and np.array_equal(f32, ref["f32"])
+    if w >= 9:
+        for a, b in ((1, w - 2), (3, 4), (w // 2, w)):
+            p8, p32 = renderer.render(0.05, 0.6, 0.4, 2, 1, u8=True, f32=True, x0=a, x1=b)
+            assert np.array_equal(p8, ref["u8"][:, a:b]) and np.array_equal(p32, ref["f32"][:, a:b])
+    if w == 130:
+        p = renderer.params(0.05, 0.6, 0.4, 2, 1)
+        streams = [renderer.stream_create() for _ in range(3)]
+        bufs = [renderer.malloc(3 * w * h) for _ in range(9)]
+        try:
+            for i, b in enumerate(bufs):
+                renderer.render_device(p, 0, w, b, None, w * h, stream=streams[i % 3])
+            for s_ in streams:
+                renderer.sync(s_)
+            for b in bufs:
+                got = np.empty((3, w, h), np.uint8); renderer.d2h(got, b)
+                assert np.array_equal(got, ref["u8"])
+        finally:
+            for s_ in streams:
+                renderer.stream_destroy(s_)
+            for b in bufs:
+                renderer.free(b)
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 4, 8])
 def test_column_slabs_assemble_bit_identical(renderer, nranks):
     """Row-tiling used for multi-GPU: N column slabs rendered separately == the single-launch frame."""

@@ -24,6 +24,7 @@ for step in "$@"; do
     trace_c4) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 200 --trace-warmup 10 --no-pmc || exit 1 ;;
     trace_c5) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 30 --trace-warmup 3 --no-pmc || exit 1 ;;
     trace_c5spp4) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --no-pmc || exit 1 ;;
+    hostpath) timeout -k 10 300 python tools/host_path_rate.py > $OUT/hostpath.log 2>&1 || exit 1; cat $OUT/hostpath.log ;;
     balance)  timeout -k 10 400 python tools/slab_balance.py > $OUT/balance.log 2>&1 || exit 1; cat $OUT/balance.log ;;
     aa)       timeout -k 10 200 python examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/aa.log 2>&1 || exit 1; cat $OUT/aa.log ;;
     fuzz)     timeout -k 10 400 python tools/fuzz_parity.py --seconds 240 --seed ${FUZZ_SEED:-201} > $OUT/fuzz.log 2>&1; rc=$?; tail -3 $OUT/fuzz.log; [ $rc -ne 0 ] && exit $rc ;;
