@@ -36,7 +36,7 @@ struct rt_ctx {
     hipStream_t stream2 = nullptr, copy_stream = nullptr;   // rt_render's chunk pipeline (created on first use)
     hipEvent_t chunk_ev[RT_RENDER_CHUNKS] = {};
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
-    int chunk_mode = 0;
+    int chunk_mode = -1;              // -1 = by destination memory type
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
@@ -718,7 +718,19 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return RT_OK;
     }
-    const bool instream = ctx->chunk_mode == 1;                 // MI355RT_CHUNK_MODE=1: every chunk on its own stream, its copy behind it
+    // Page-locked destinations (rt_host_alloc): every chunk on its own stream (descending priority) with its copy queued
+    // behind it in the same stream — no cross-stream event between kernel and copy (measured 0.213 ms per 1080p uint8
+    // frame against 0.222).  Pageable destinations: the runtime stages those copies on the calling thread, so the
+    // chunks alternate on two streams and the copies wait on a third behind events (0.23 ms; in-stream: 0.37).
+    // MI355RT_CHUNK_MODE=0/1 forces one scheme.
+    bool instream = false;
+    {
+        hipPointerAttribute_t at;
+        void *probe = out_u8 ? (void *)out_u8 : (void *)out_f32;
+        if (hipPointerGetAttributes(&at, probe) == hipSuccess) instream = (at.type == hipMemoryTypeHost);
+        else (void)hipGetLastError();                           // plain malloc memory: "invalid value", not an error here
+        if (ctx->chunk_mode >= 0) instream = ctx->chunk_mode == 1;
+    }
     if (!ctx->copy_stream) {
         RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));

@@ -32,7 +32,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         res.append(f"bare-d2h-u8/{'pinned' if pinned else 'pageable'} {(time.perf_counter() - t0) / 30 * 1e3:.3f}")
     print(f"chunks={os.environ.get('MI355RT_CHUNKS')}: " + "  ".join(res), flush=True)
 else:
-    for mode in ("0", "1"):
-        for ch in ("1", "2", "3", "4", "6"):
+    for mode in ("-1", "0", "1"):                      # -1: by destination memory type (the default)
+        for ch in ("1", "4"):
             print("mode", mode, end=" ", flush=True)
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, MI355RT_CHUNKS=ch, MI355RT_CHUNK_MODE=mode))
