@@ -81,6 +81,8 @@ typedef enum rt_status {
 #define RT_FLAG_AA_PER_PIXEL 32 /* RT_AA_REFERENCE: trace all nine taps of every pixel (what the reference does, kernels.py:29-65)
                                   instead of tracing each half-pixel lattice sample once and summing nine per pixel — the
                                   default on the closed-form grid, same bytes, 4 instead of 9 samples per pixel */
+#define RT_FLAG_NO_BUNDLES 64 /* scenes with 24 spheres or more: skip the wave-level bundle pre-cull (one lane-per-sphere pass per
+                                query in front of the per-ray cull, rt_device.h).  Same pixels; for A/B timing. */
 #define RT_FLAG_COUNT_RAYS 16 /* run the counting instantiation of the kernel (slower: registers instead of LDS-parked
                                 state): adds this launch's ray counts to the context's rt_stats.  Same pixels. */
 
@@ -128,6 +130,10 @@ typedef struct rt_stats {
     uint64_t hits;
     uint64_t shadow_traced;
     uint64_t shadow_skipped;
+    /* per bounce b (0 = primary rays): wavefronts that traced it and the lanes of those that carried a ray —
+     * bounce_lanes[b] / (64 bounce_waves[b]) is the SIMD lane utilisation of that bounce */
+    uint64_t bounce_waves[RT_MAX_DEPTH + 1];
+    uint64_t bounce_lanes[RT_MAX_DEPTH + 1];
 } rt_stats;
 
 int rt_abi_version(void);

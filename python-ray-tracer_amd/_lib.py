@@ -11,7 +11,7 @@ RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 RT_AA_NONE, RT_AA_REFERENCE, RT_AA_STOCHASTIC = 0, 1, 2
 RT_MAX_SPP = 64
-RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB, RT_FLAG_NO_FEEDBACK, RT_FLAG_U8_HWC, RT_FLAG_COUNT_RAYS, RT_FLAG_AA_PER_PIXEL = 1, 2, 4, 8, 16, 32
+RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB, RT_FLAG_NO_FEEDBACK, RT_FLAG_U8_HWC, RT_FLAG_COUNT_RAYS, RT_FLAG_AA_PER_PIXEL, RT_FLAG_NO_BUNDLES = 1, 2, 4, 8, 16, 32, 64
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_DEVICE", -4: "RT_ERR_STATE", -5: "RT_ERR_ALLOC"}
 
@@ -28,7 +28,8 @@ class rt_kernel_info(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("launches", "launches_measuring", "launches_settled", "table_builds",
-                                          "closest_queries", "hits", "shadow_traced", "shadow_skipped")]
+                                          "closest_queries", "hits", "shadow_traced", "shadow_skipped")] + \
+               [("bounce_waves", C.c_uint64 * (RT_MAX_DEPTH + 1)), ("bounce_lanes", C.c_uint64 * (RT_MAX_DEPTH + 1))]
 
 
 # name -> (restype, argtypes); must list every function include/mi355rt.h declares.

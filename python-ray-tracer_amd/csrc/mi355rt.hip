@@ -28,6 +28,7 @@ struct Buf {
 }  // namespace
 
 #define RT_FEEDBACK_SLOTS 8
+#define RT_COUNT_WORDS (4 + 2 * (RT_MAX_DEPTH + 1))   /* ray counters + per bounce {waves, alive lanes} */
 #define RT_RENDER_CHUNKS 8   /* upper bound; the pipeline uses ctx->render_chunks of them */
 
 struct rt_ctx {
@@ -145,6 +146,14 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     }
     if (x0 < 0 || x1 > ctx->w || x0 >= x1) return fail(ctx, RT_ERR_BAD_ARG, "column range must satisfy 0 <= x0 < x1 <= w");
     return RT_OK;
+}
+
+// instantiations with the bundle pre-cull (scenes with rt::BND_MIN_SPHERES spheres or more; workgroups of 4 only)
+const void *bundle_variant(bool aa, bool park, bool lattice)
+{
+    if (lattice) return park ? (const void *)rt::render_kernel<false, true, 4, false, true, true> : (const void *)rt::render_kernel<false, false, 4, false, true, true>;
+    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4, false, false, true> : (const void *)rt::render_kernel<true, false, 4, false, false, true>)
+              : (park ? (const void *)rt::render_kernel<false, true, 4, false, false, true> : (const void *)rt::render_kernel<false, false, 4, false, false, true>);
 }
 
 const void *lattice_variant(bool park, int wpw, bool count = false)     // the plain kernel over the half-pixel lattice (RT_AA_REFERENCE)
@@ -323,12 +332,16 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool aa = k.aa != 0;
     const bool count = (p->flags & RT_FLAG_COUNT_RAYS) != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    const int wpw = (image <= 4608 && !count) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
+    // bundle pre-cull (rt_device.h): scenes with enough spheres for a lane-per-sphere pass to pay; not with the counters
+    // (clustered scenes, S > rt::CLUSTER_MIN: measured slower with it — config 5: 22.8 against 20.6 ms; their deep, incoherent
+    // bounces dominate and gain nothing from a bundle bound)
+    const bool bnd = ctx->S >= rt::BND_MIN_SPHERES && ctx->NC == 0 && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
+    const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
-    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bnd);
     const bool park = !count && lds_park * (24 / wpw) <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt);
-    const void *fn = lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count);
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bnd);
+    const void *fn = bnd ? bundle_variant(aa, park, lattice) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -337,13 +350,15 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         for (int v = 0; v < 4; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(v & 1, (v & 2) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 6; ++v)
+            RT_HIP(ctx, hipFuncSetAttribute(bundle_variant(v & 1, v & 2, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
     }
     if (count) {
         if (!ctx->counts.p) {
-            int rc0 = ensure(ctx, ctx->counts, 4 * sizeof(unsigned long long));
+            int rc0 = ensure(ctx, ctx->counts, RT_COUNT_WORDS * sizeof(unsigned long long));
             if (rc0 != RT_OK) return rc0;
-            RT_HIP(ctx, hipMemsetAsync(ctx->counts.p, 0, 4 * sizeof(unsigned long long), stream));
+            RT_HIP(ctx, hipMemsetAsync(ctx->counts.p, 0, RT_COUNT_WORDS * sizeof(unsigned long long), stream));
         }
         k.ray_counts = (unsigned long long *)ctx->counts.p;
     }
@@ -354,7 +369,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
-    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw;
+    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (bnd ? 16 : 0);
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
     if (!fsel) {                                               // a free slot, else the least recently used geometry
@@ -934,13 +949,14 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out)
     if (!ctx) return RT_ERR_BAD_ARG;
     if (!out) return fail(ctx, RT_ERR_BAD_ARG, "stats is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[RT_COUNT_WORDS] = {0};
     if (ctx->counts.p) {                                        // counting launches may be in flight on any stream
         RT_HIP(ctx, hipDeviceSynchronize());
         RT_HIP(ctx, hipMemcpy(c, ctx->counts.p, sizeof c, hipMemcpyDeviceToHost));
     }
     *out = ctx->stats;
     out->closest_queries = c[0]; out->shadow_traced = c[1]; out->shadow_skipped = c[2]; out->hits = c[3];
+    for (int b = 0; b <= RT_MAX_DEPTH; ++b) { out->bounce_waves[b] = c[4 + 2 * b]; out->bounce_lanes[b] = c[5 + 2 * b]; }
     return RT_OK;
 }
 
@@ -950,7 +966,7 @@ int rt_reset_stats(rt_ctx *ctx)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->counts.p) {
         RT_HIP(ctx, hipDeviceSynchronize());
-        RT_HIP(ctx, hipMemset(ctx->counts.p, 0, 4 * sizeof(unsigned long long)));
+        RT_HIP(ctx, hipMemset(ctx->counts.p, 0, RT_COUNT_WORDS * sizeof(unsigned long long)));
     }
     ctx->stats = rt_stats{};
     return RT_OK;

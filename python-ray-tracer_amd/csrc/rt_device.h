@@ -249,6 +249,7 @@ struct Lds {
     const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
     const float *ctab;     // anchors x NCp x CULL_STRIDE: cluster bounding spheres, anchored form
     int NC;
+    unsigned long long *bnd;   // BND kernels: this wave's bundle area (BND_WORDS words): candidate masks + the hit-point ball
     double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
                            // slots 0-2 the running colour of the current sample, 3-5 the incoming direction
                            // during the light loop, 6-8 (AA kernel only) the tap sums — kept out of VGPRs that would stay
@@ -310,9 +311,6 @@ __device__ __forceinline__ bool cull_anchored(const f4 e, const RayF &q)
 // no certificate.  Straight-line float32 work with no dependence between spheres; the mask is
 // wave-uniform (it is built from ballots), so phase 2 — the float64 test — runs only for set bits.
 // self: the sphere a shadow ray starts on (-1: none), certified by the origin form's "behind" test.
-__device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const V3 &o, const V3 &R, float extent2, int self);
-
 // origin form: line-miss or behind certificate
 __device__ __forceinline__ bool cull_origin(const f4 c, const RayF &q)
 {
@@ -369,6 +367,172 @@ __device__ __forceinline__ int order_bucket(unsigned c)
 // sphere slots in the float32 tables: whole clusters when the scene is clustered, else a multiple of 4
 __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTER : pad4(S); }
 
+
+// ---------------------------------------------------------------------------------------------
+// Bundle pre-cull (scenes with BND_MIN_SPHERES spheres or more).  The per-ray cull above costs 4 (anchored) to 17
+// (origin form) VALU instructions per sphere or cluster bound and RAY; but the 64 rays of a wavefront are a tight
+// bundle (an 8x8 pixel tile's primary rays; the shadow rays from one small patch of surface to one light; the
+// reflections off that patch), and most of the scene is nowhere near it.  So once per query the wave runs ONE pass
+// per 64 spheres (or 64 cluster bounds) with lane = sphere, testing the sphere against a conservative bound of the
+// whole bundle, and the per-ray cull then only looks at the candidates that pass left (typically 0-4 of 64).
+// Like the per-ray cull this never decides a hit: it only removes spheres NO ray of the bundle can hit, so the float64
+// tests that remain, and with them every result bit, are unchanged.
+//
+//  * anchored bundle — lines through a common point A (camera, or the light a shadow query points at) whose
+//    directions lie within angle g of an axis X.  A line through A with direction d hits sphere (c, r) iff the angle
+//    between the line and u = c - A is at most b = asin(r/|u|); line angles obey the triangle inequality, so a hit
+//    implies angle(X, u) <= g + b, i.e. the sphere is culled when |u.X| < |u| cos(g + b) = cos g * T - sin g * r with
+//    T = sqrt(|u|^2 - r^2) the tangent length — which is the tau the anchored cull table already holds (rounded down,
+//    margins subtracted).  Lanes read {A - c, tau} from that table and r^2 from the float32 sphere table.
+//  * free bundle — origins within Ball(C, rho), directions within angle g < 90 deg of X (reflection rays).  With u = c - C,
+//    D = |u|: a forward hit from origin o needs angle(d, c - o) <= asin(r/|c - o|), |c - o| >= D - rho, and
+//    angle(c - o, u) <= asin(rho/D); asin is superadditive on [0,1], so a hit implies
+//    angle(X, u) <= g + asin(s), s = (r + rho)/(D - rho) (required < 1): culled when (u.X)/D < cos g sqrt(1 - s^2) - sin g * s.
+//    (Spheres behind the bundle are culled too: the angle is measured from the forward axis.)
+//  The shadow rays of a hit-point ball toward light A form the anchored bundle X = (C - A)/|C - A|, sin g = rho/|C - A|.
+// Everything is float32 with the bound inflated where it is formed (rho, sin g rounded up by 2^-10 relative plus an
+// absolute slack; cos g rounded down) and 2^-16 taken off the right-hand side — the compared quantities are
+// (sums of three) products of magnitude <= |u| whose rounding errors are below 2^-21 |u|; s is capped at 0.98 so that
+// sqrt(1 - s^2) is well conditioned.  NaNs fail every "cull" comparison: a NaN bundle keeps every sphere.
+// All of it runs in wave-uniform control flow with all 64 lanes executing (lanes without a ray contribute neutral
+// values), between the divergent parts of trace_bounce; the masks wait in the wave's LDS words until the queries read them.
+// ---------------------------------------------------------------------------------------------
+constexpr int BND_MIN_SPHERES = 24;      // below this the per-ray cull is cheaper than the passes
+constexpr int BND_LIGHTS = 8;            // lights with their own candidate masks (further lights: no pre-cull)
+constexpr int BND_WORDS = 2 + 2 * BND_LIGHTS + 2;   // closest-hit masks (2), per light (2 each), ball {C.xyz, rho} (2 words)
+struct Cand { unsigned long long w0, w1; bool on; };      // candidates of one query: spheres (flat scene) or clusters; 128 of them at most
+
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// max over the wave of non-negative values (0 is neutral); uniform control flow only.  Four DPP steps leave every
+// row of 16 lanes holding its maximum (xor 1, xor 2, mirror of 8, mirror of 16), four readlanes combine the rows.
+__device__ __forceinline__ float wave_max_nonneg(float v)
+{
+    v = __builtin_fmaxf(v, dpp_get<0xB1>(v));             // quad_perm [1,0,3,2]
+    v = __builtin_fmaxf(v, dpp_get<0x4E>(v));             // quad_perm [2,3,0,1]
+    v = __builtin_fmaxf(v, dpp_get<0x141>(v));            // row_half_mirror
+    v = __builtin_fmaxf(v, dpp_get<0x140>(v));            // row_mirror
+    return __builtin_fmaxf(__builtin_fmaxf(readlane_f(v, 0), readlane_f(v, 16)), __builtin_fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+
+struct Cone { float x, y, z, cosg, sing; bool ok; };
+struct Ball { float x, y, z, rho; bool ok; };
+// wave-uniform values belong in scalar registers (the compiler keeps the result of VALU arithmetic in a VGPR even when
+// every lane holds the same value; registers decide occupancy here)
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+// the lane whose ray stands for the bundle's middle: the tile's centre pixel if it takes part, else the first that does
+__device__ __forceinline__ int bundle_lane(unsigned long long part) { return ((part >> 27) & 1ull) ? 27 : (int)__builtin_ctzll(part | (1ull << 63)); }
+
+// smallest cone (axis = one lane's direction) around the unit directions of the lanes in `part`.  |d x X| is the sine
+// of the angle for a direction within 90 degrees of the axis AND for its opposite: a direction with d.X <= 0 is
+// counted as sin = 1, which disqualifies the bundle (lines through an anchor are undirected, but free rays are not).
+__device__ __forceinline__ Cone direction_cone(bool part, const V3 &d)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(part);
+    const int l = bundle_lane(m);
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    Cone c;
+    c.x = readlane_f(dx, l); c.y = readlane_f(dy, l); c.z = readlane_f(dz, l);
+    const float kx = dy * c.z - dz * c.y, ky = dz * c.x - dx * c.z, kz = dx * c.y - dy * c.x;     // |d x X| = sin(angle)
+    const float dt = __builtin_fmaf(dz, c.z, __builtin_fmaf(dy, c.y, dx * c.x));
+    const float s2 = wave_max_nonneg(part ? (dt > 0.0f ? __builtin_fmaf(kz, kz, __builtin_fmaf(ky, ky, kx * kx)) : 1.0f) : 0.0f);
+    c.sing = uni(__builtin_fmaf(__builtin_sqrtf(s2), 1.0f + 0x1p-10f, 0x1p-20f));                  // rounded up
+    c.cosg = uni(__builtin_sqrtf(__builtin_fmaxf(1.0f - c.sing * c.sing, 0.0f)) * (1.0f - 0x1p-20f));  // rounded down
+    c.ok = (m != 0ull) && (c.sing < 0.5f);                 // directions more than 30 degrees apart: not a bundle
+    return c;
+}
+
+// ball (centre = one lane's point) around the points of the lanes in `part`; slack: float32 rounding of the coordinates
+// and the 0.0002 steps the reference takes off a surface (trace.py:82-83, :110)
+__device__ __forceinline__ Ball point_ball(bool part, const V3 &P)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(part);
+    const int l = bundle_lane(m);
+    const float px = (float)P.x, py = (float)P.y, pz = (float)P.z;
+    Ball b;
+    b.x = readlane_f(px, l); b.y = readlane_f(py, l); b.z = readlane_f(pz, l);
+    const float ex = px - b.x, ey = py - b.y, ez = pz - b.z;
+    const float d2 = wave_max_nonneg(part ? __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) : 0.0f);
+    const float mag = __builtin_fabsf(b.x) + __builtin_fabsf(b.y) + __builtin_fabsf(b.z);
+    b.rho = uni(__builtin_fmaf(__builtin_sqrtf(d2), 1.0f + 0x1p-10f, __builtin_fmaf(mag, 0x1p-18f, 0.001f)));
+    b.ok = (m != 0ull) && (b.rho == b.rho) && (b.rho < 0x1p60f);
+    return b;
+}
+
+// the anchored bundle of the shadow rays from a ball of hit points toward the point A
+__device__ __forceinline__ Cone cone_toward(const Ball &b, float ax, float ay, float az)
+{
+    const float ux = b.x - ax, uy = b.y - ay, uz = b.z - az;
+    const float d2 = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+    const float inv = __builtin_amdgcn_rsqf(d2);
+    Cone c;
+    c.x = uni(ux * inv); c.y = uni(uy * inv); c.z = uni(uz * inv);
+    c.sing = uni(__builtin_fmaf(b.rho * inv, 1.0f + 0x1p-10f, 0x1p-20f));
+    c.cosg = uni(__builtin_sqrtf(__builtin_fmaxf(1.0f - c.sing * c.sing, 0.0f)) * (1.0f - 0x1p-20f));
+    c.ok = b.ok && (c.sing < 0.5f);                         // (NaN fails)
+    return c;
+}
+
+// One pass, lane = item (sphere or cluster bound) first + lane, items [first, first + count): bit set = candidate.
+// otab: {cx,cy,cz,r2} entries; atab: the anchor's {A - c, tau} entries (anchored form only).
+template <bool ANCH>
+__device__ __forceinline__ unsigned long long bundle_pass(const float *otab, const float *atab, int first, int count,
+                                                          const Cone &k, const Ball &b)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool in = lane < count;
+    const int i = first + (in ? lane : 0);
+    const f4 c = *reinterpret_cast<lds_cf4 *>((size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const float *)(otab + 4 * i));
+    const float r = __builtin_fmaf(__builtin_sqrtf(c[3]), 1.0f + 0x1p-20f, 0x1p-30f);
+    bool cull;
+    if constexpr (ANCH) {
+        const f4 e = *reinterpret_cast<lds_cf4 *>((size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const float *)(atab + 4 * i));
+        const float lhs = __builtin_fabsf(__builtin_fmaf(e[2], k.z, __builtin_fmaf(e[1], k.y, e[0] * k.x)));
+        const float rhs = __builtin_fmaf(k.cosg, e[3], -(k.sing * r));
+        cull = lhs < rhs - 0x1p-16f * (e[3] + r);
+    } else {
+        const float ux = c[0] - b.x, uy = c[1] - b.y, uz = c[2] - b.z;
+        const float D2 = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+        const float rD = __builtin_amdgcn_rsqf(D2);
+        const float t = D2 * rD - b.rho;                                        // D - rho
+        const float sv = (r + b.rho) * __builtin_amdgcn_rcpf(t) * (1.0f + 0x1p-20f);
+        const float cb = __builtin_sqrtf(__builtin_fmaxf(1.0f - sv * sv, 0.0f));
+        const float lhs = __builtin_fmaf(uz, k.z, __builtin_fmaf(uy, k.y, ux * k.x)) * rD;
+        const float rhs = __builtin_fmaf(k.cosg, cb, -(k.sing * sv));
+        cull = (t > 0.0f) && (sv < 0.98f) && (lhs < rhs - 0x1p-16f);
+    }
+    return __builtin_amdgcn_ballot_w64(in && !cull);
+}
+
+// The candidate words of one query: spheres 0..127 of a flat scene, or the cluster bounds of a clustered one.
+template <bool ANCH>
+__device__ __forceinline__ void bundle_candidates(const Lds &lds, int S, int anchor, const Cone &k, const Ball &b,
+                                                  unsigned long long &w0, unsigned long long &w1)
+{
+    w0 = ~0ull; w1 = ~0ull;
+    if (!(k.ok && (ANCH || b.ok))) return;                                      // wave-uniform
+    const int Sp = padS(S, lds.NC), NCp = pad4(lds.NC);
+    const int items = lds.NC > 0 ? lds.NC : S;
+    const float *otab = lds.NC > 0 ? lds.csph32 : lds.sph32;
+    const float *atab = lds.NC > 0 ? lds.ctab + (size_t)anchor * NCp * CULL_STRIDE : lds.tab + (size_t)anchor * Sp * CULL_STRIDE;
+    w0 = bundle_pass<ANCH>(otab, atab, 0, items < 64 ? items : 64, k, b);
+    w1 = items > 64 ? bundle_pass<ANCH>(otab, atab, 64, items - 64 < 64 ? items - 64 : 64, k, b) : 0ull;
+}
+
+__device__ __forceinline__ void bnd_store(const Lds &lds, int word, unsigned long long v)
+{
+    if ((threadIdx.x & 63u) == 0u) ((volatile unsigned long long *)lds.bnd)[word] = v;
+}
+__device__ __forceinline__ unsigned long long bnd_load(const Lds &lds, int word)
+{
+    const unsigned long long v = ((volatile unsigned long long *)lds.bnd)[word];
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // Certificates of 4 consecutive table entries -> 4 mask bits (bit u set = some live lane has no certificate).
 // The tables are padded with entries that always certify a miss (tau = +inf, r2 = -inf), so groups of 4 need no
 // bounds handling and use immediate LDS offsets.
@@ -407,7 +571,7 @@ __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel
 // flow on scalar masks.
 template <bool ANCH, bool SELF>
 __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S, int anchor, int k0, int n,
-                                                          const RayF &q, int selfj)
+                                                          const RayF &q, int selfj, const Cand &cand)
 {
     unsigned long long mask = 0ull;
     const int Sp = padS(S, lds.NC);
@@ -416,6 +580,11 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
         lds_cf4 *cbase = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0);
         unsigned cm = 0;
+        if (cand.on) {                                                        // only the bundle's candidate clusters get the per-ray test
+            const unsigned bits = (unsigned)(((c0 < 64 ? cand.w0 : cand.w1) >> (c0 & 63)) & 0xFFull);
+            for (int j = 0; j < nc; j += 4) if ((bits >> j) & 0xFu) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
+            cm &= bits;
+        } else
         for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
@@ -425,6 +594,15 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
             const unsigned lohi = cull4<ANCH, SELF>(sbase + jb, q, selfj - jb, hi);
             mask |= (unsigned long long)lohi << jb;
         }
+    } else if (cand.on) {                                                     // flat scene: groups of 4 holding a candidate
+        const unsigned long long cw = (k0 == 0 ? cand.w0 : cand.w1) & ((n == 64) ? ~0ull : ((1ull << n) - 1ull));
+        unsigned long long gm = (cw | (cw >> 1) | (cw >> 2) | (cw >> 3)) & 0x1111111111111111ull;
+        while (gm) {
+            const int j = __builtin_ctzll(gm);
+            gm &= gm - 1ull;
+            mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
+        }
+        mask &= cw;
     } else {
         const int npad = pad4(n);
         for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
@@ -433,7 +611,7 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
 }
 
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const V3 &o, const V3 &R, float extent2, int self)
+                                                        const V3 &o, const V3 &R, float extent2, int self, const Cand &cd)
 {
     RayF q = make_rayf_dir(R);
     if (anchor >= 0) {
@@ -443,12 +621,12 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
             const float *cs = lds.sph32 + 4 * self;
             const bool self_culled = cand ? cull_origin(f4{cs[0], cs[1], cs[2], cs[3]}, q) : false;
             if (__builtin_amdgcn_ballot_w64(self_culled) != 0ull)
-                return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1);
+                return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1, cd);
         }
-        return cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1);
+        return cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1, cd);
     }
     add_origin(q, o, extent2);
-    return cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1);
+    return cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1, cd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,12 +669,17 @@ __device__ __forceinline__ void plane_den_num(const double *__restrict__ g, int 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
+template <bool BND>
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
-                                            double &t_out, int &idx_out, int &type_out)
+                                            double &t_out, int &idx_out, int &type_out, const Cand &cand)
 {
-    const int S = p.S, P = p.P;
-    const V3 R = renormalize_unit(d);                         // == normalize(d), intersections.py:13
-    const double a = dot3(R, R);
+    const int P = p.P;
+    // the bundle pre-cull left no sphere any lane's ray could reach: the sphere part — including the re-normalised
+    // direction only it uses — is skipped (wave-uniform)
+    const int S = (BND && (cand.w0 | cand.w1) == 0ull) ? 0 : p.S;
+    V3 R{0.0, 0.0, 0.0};
+    double a = 1.0;
+    if (!BND || S > 0) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
 #if RT_PREFILTER
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
@@ -507,7 +690,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #if RT_PREFILTER
       unsigned long long mask;
       // the float32 ray is rebuilt per chunk so that it is not live during the float64 phase
-      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, -1);
+      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, -1, cand);
       mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);       // padding slots certify themselves, except to a NaN ray
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
@@ -552,7 +735,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
         const double t = bestn / a;                           // :31 / :36, once per query
         if (best > t && t > 0.0) { best = t; idx = bidx; type = HIT_SPHERE; }
     }
-    const double *pl = lds.rec + S * SPH_STRIDE;
+    const double *pl = lds.rec + p.S * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {                             // intersections.py:41-68
         const double *g = pl + k * PL_STRIDE;
         double den, num;
@@ -569,11 +752,14 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 // Called with the lanes that need the answer active; returns true if occluded.
 // anchor = cull-table index of the light the ray points at; self = index of the sphere the ray
 // starts on (-1: a plane), whose miss is certified by the origin-form "behind" test.
-__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self)
+template <bool BND>
+__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const Cand &cand)
 {
-    const int S = p.S, P = p.P;
-    const V3 R = renormalize_unit(d);                         // == normalize(d), intersections.py:13
-    const double a = dot3(R, R);
+    const int P = p.P;
+    const int S = (BND && (cand.w0 | cand.w1) == 0ull) ? 0 : p.S;           // no candidate sphere for any lane (wave-uniform)
+    V3 R{0.0, 0.0, 0.0};
+    double a = 1.0;
+    if (!BND || S > 0) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
     const bool a_sane = (a > 0.999999 && a < 1.000001);
     bool occ = false;
 #if RT_PREFILTER
@@ -584,7 +770,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
-      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, self);
+      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, self, cand);
       mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
@@ -618,7 +804,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         }
       }
     }
-    const double *pl = lds.rec + S * SPH_STRIDE;
+    const double *pl = lds.rec + p.S * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         if (!occ) {
@@ -664,7 +850,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
-    if (alive) closest_hit(lds, p, o, d, anchor, t, idx, type);               // :53 (idle lanes masked off)
+    if (alive) closest_hit<false>(lds, p, o, d, anchor, t, idx, type, Cand{0ull, 0ull, false});   // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
     if (alive) {
@@ -701,7 +887,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             // so lanes with k <= 0 (light behind the surface) do not ask.
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
-                const bool occluded = any_hit(lds, p, Pt, Ld, 1 + m, self);
+                const bool occluded = any_hit<false>(lds, p, Pt, Ld, 1 + m, self, Cand{0ull, 0ull, false});
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -715,15 +901,126 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     }
 }
 
-// trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
+
+// trace_bounce for the BND instantiations (scenes with BND_MIN_SPHERES spheres or more): the same per-lane arithmetic,
+// cut into its divergent parts so that the bundle passes between them run with all 64 lanes:
+//   closest hit (candidates prepared by the previous bounce / by sample() for the primary rays)
+//   | hit point, normal                       — lanes that hit
+//   | ball of the hit points -> one candidate pass per light       — whole wave
+//   | light loop, reflection                   — lanes that hit
+//   | cone of the reflected directions -> candidates of the next closest-hit query      — whole wave
 template <bool PARK, int WGT, bool COUNT>
+__device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &p, bool &alive, int anchor,
+                                                 V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt, bool last)
+{
+    const int S = p.S, P = p.P, L = p.L;
+    rgb = V3{0.0, 0.0, 0.0};
+    double t = 999.0; int idx = -1, type = HIT_NONE;
+    cnt.closest(alive);
+    {
+        const Cand cc{bnd_load(lds, 0), bnd_load(lds, 1), true};
+        if (alive) closest_hit<true>(lds, p, o, d, anchor, t, idx, type, cc);       // :53
+    }
+    alive = alive && (type != HIT_NONE);                                      // :56-57
+    cnt.hit(alive);
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;                   // wave-uniform
+    V3 Pt{0.0, 0.0, 0.0}, N{0.0, 0.0, 0.0};
+    int coff = 0, self = -1;
+    Park3<PARK, WGT> dpark(lds.acc, 1);
+    if (alive) {
+        Pt = V3{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                 // :60
+        coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : S * SPH_STRIDE + idx * PL_STRIDE + 12;
+        V3 bN;
+        if (type == HIT_SPHERE) {                                             // :63-66
+            const double *g = lds.rec + idx * SPH_STRIDE;
+            N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});
+            bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
+        } else {                                                              // :68-71
+            const double *g = lds.rec + S * SPH_STRIDE + idx * PL_STRIDE;
+            N = V3{g[6], g[7], g[8]};
+            bN = V3{g[9], g[10], g[11]};
+        }
+        Pt = V3{Pt.x + bN.x, Pt.y + bN.y, Pt.z + bN.z};                       // :82-83
+        self = (type == HIT_SPHERE) ? idx : -1;
+        dpark.set(d);
+    }
+    // ---- whole wave: the hit points' ball and, per light, the spheres / clusters some shadow ray might reach
+    const Ball ball = point_ball(alive, Pt);
+    const int nl = L < BND_LIGHTS ? L : BND_LIGHTS;
+    const double *lt = lds.rec + S * SPH_STRIDE + P * PL_STRIDE;
+    for (int m = 0; m < nl; ++m) {
+        const double *g = lt + m * LT_STRIDE;
+        const Cone k = cone_toward(ball, (float)g[0], (float)g[1], (float)g[2]);
+        unsigned long long w0, w1;
+        if (p.anchors > 0) bundle_candidates<true>(lds, S, 1 + m, k, ball, w0, w1);
+        else bundle_candidates<false>(lds, S, 0, Cone{-k.x, -k.y, -k.z, k.cosg, k.sing, k.ok}, ball, w0, w1);   // the rays run from the ball toward the light
+        bnd_store(lds, 2 + 2 * m, w0); bnd_store(lds, 3 + 2 * m, w1);
+    }
+    if (alive) {
+        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.rec + coff;
+        V3 colr{0.0, 0.0, 0.0};
+        if constexpr (!PARK) colr = V3{lds.rec[coff], lds.rec[coff + 1], lds.rec[coff + 2]};
+        auto col = [&](int c) -> double { if constexpr (PARK) return colp[c]; else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z); };
+        rgb = V3{p.amb * col(0), p.amb * col(1), p.amb * col(2)};             // :77
+        for (int m = 0; m < L; ++m) {                                         // :86-102
+            const double *g = lt + m * LT_STRIDE;
+            const V3 Ld = normalize3(V3{g[0] - Pt.x, g[1] - Pt.y, g[2] - Pt.z});
+            const double k = p.lamb * dot3(Ld, N);                            // :99
+            cnt.shadow(true, k > 0.0);
+            if (k > 0.0) {
+                const Cand cs = m < nl ? Cand{bnd_load(lds, 2 + 2 * m), bnd_load(lds, 3 + 2 * m), true} : Cand{~0ull, ~0ull, false};
+                const bool occluded = any_hit<true>(lds, p, Pt, Ld, 1 + m, self, cs);
+                if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
+            }
+        }
+        d = dpark.get();
+        const double c2 = -2.0 * dot3(d, N);                                  // common.py:113-120
+        const V3 Rd = renormalize_unit(V3{d.x + c2 * N.x, d.y + c2 * N.y, d.z + c2 * N.z});
+        o = V3{Pt.x + 0.0002 * Rd.x, Pt.y + 0.0002 * Rd.y, Pt.z + 0.0002 * Rd.z};   // :110
+        d = Rd;
+    }
+    // ---- whole wave: the reflected rays leave the ball within a cone -> candidates of the next closest-hit query
+    if (!last) {
+        const Cone kr = direction_cone(alive, d);
+        unsigned long long w0, w1;
+        bundle_candidates<false>(lds, S, 0, kr, ball, w0, w1);
+        bnd_store(lds, 0, w0); bnd_store(lds, 1, w1);
+    }
+}
+
+// the primary rays of a sample: lines through the camera (anchor 0) within a cone -> candidates of the first query
+__device__ __forceinline__ void primary_bundle(const Lds &lds, const KParams &p, bool alive, const V3 &d)
+{
+    const Cone k = direction_cone(alive, d);
+    unsigned long long w0, w1;
+    if (p.anchors > 0) bundle_candidates<true>(lds, p.S, 0, k, Ball{0.0f, 0.0f, 0.0f, 0.0f, false}, w0, w1);
+    else {
+        const float cx = (float)p.cam_o[0], cy = (float)p.cam_o[1], cz = (float)p.cam_o[2];
+        const Ball b{cx, cy, cz, (__builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz)) * 0x1p-18f + 0x1p-20f, true};
+        bundle_candidates<false>(lds, p.S, 0, k, b, w0, w1);
+    }
+    bnd_store(lds, 0, w0); bnd_store(lds, 1, w1);
+}
+
+// trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
+template <bool PARK, int WGT, bool COUNT, bool BND>
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
     Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
+    if constexpr (BND) primary_bundle(lds, p, alive, d);
     for (int b = 0; b <= p.depth; ++b) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;                                   // wave-uniform exit
+        if constexpr (COUNT) {                                                // lane utilisation per bounce: waves entering, lanes alive
+            const unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
+            if ((threadIdx.x & 63u) == 0u && p.ray_counts) {
+                atomicAdd(&p.ray_counts[4 + 2 * b], 1ull);
+                atomicAdd(&p.ray_counts[5 + 2 * b], (unsigned long long)__builtin_popcountll(am));
+            }
+        }
         V3 rgb;
+        if constexpr (BND) trace_bounce_bnd<PARK, WGT, COUNT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt, b == p.depth);
+        else
         trace_bounce<PARK, WGT, COUNT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
@@ -812,11 +1109,12 @@ __device__ __forceinline__ void store_pixel(const KParams &p, long long off, dou
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
 __host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x workgroup-size doubles
 __host__ __device__ inline int lds_offset_words(bool park, int wgt) { return park ? wgt : 0; }    // + one int32 per thread: the pixel offset
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt)
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool bnd = false)
 {
     return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
            ((size_t)lds_offset_words(park, wgt) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
-           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + 16;   // + workgroup cost/arrival words
+           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + 16 +   // + workgroup cost/arrival words
+           (bnd ? (size_t)(wgt / 64) * BND_WORDS * sizeof(unsigned long long) : 0);          // + the waves' bundle words
 }
 
 // floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table
@@ -886,14 +1184,17 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
-template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false>
+template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, bool BND = false>
 #ifndef RT_W_PARK
 #define RT_W_PARK 7
 #endif
 #ifndef RT_W_AAPARK
 #define RT_W_AAPARK 7   // 72 VGPRs with a few spills (76 B/lane of scratch) still beat 5 waves/SIMD without: -9 %
 #endif
-__global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
+#ifndef RT_W_BND
+#define RT_W_BND 6      // the bundle variants keep a few more values live between the divergent parts
+#endif
+__global__ __launch_bounds__(64 * WPW, (BND && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
     extern __shared__ double lds_raw[];
@@ -906,6 +1207,7 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
     float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
     float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
     unsigned *wgstat = reinterpret_cast<unsigned *>(ctab + (size_t)p.anchors * NCp * CULL_STRIDE);   // {cycles, waves done}
+    unsigned long long *bnd = reinterpret_cast<unsigned long long *>(wgstat + 4) + (threadIdx.x >> 6) * BND_WORDS;   // BND: this wave's words
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
         // used to be computed here, by every workgroup: 3 % of the frame's VALU instructions and a second barrier.)
@@ -918,7 +1220,7 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
 #endif
     }
     __syncthreads();
-    const Lds lds{lds_raw, sph32, tab, csph32, ctab, p.NC, accum};
+    const Lds lds{lds_raw, sph32, tab, csph32, ctab, p.NC, bnd, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
@@ -945,7 +1247,7 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
     RayCount<COUNT> cnt;
     double R, G, B;
     if constexpr (!AA) {
-        const V3 c = sample<PARK, WG_THREADS, COUNT>(lds, p, inb, o, primary_dir(p, LAT ? lattice_P(p, xc, yc) : pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
+        const V3 c = sample<PARK, WG_THREADS, COUNT, BND>(lds, p, inb, o, primary_dir(p, LAT ? lattice_P(p, xc, yc) : pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
         R = c.x; G = c.y; B = c.z;
     } else {
         // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
@@ -973,7 +1275,7 @@ __global__ __launch_bounds__(64 * WPW, (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? 
                 const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
                 Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
             }
-            const V3 s = sample<PARK, WG_THREADS, COUNT>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt), cnt);   // :26 / :56
+            const V3 s = sample<PARK, WG_THREADS, COUNT, BND>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt), cnt);   // :26 / :56
             if (tap == 0) taps.set(s);
             else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.y, a.z + s.z}); }
             else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.z, a.z + s.y}); }   // :58-60 (G += B_s; B += G_s)

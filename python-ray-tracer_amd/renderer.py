@@ -224,7 +224,7 @@ class Renderer:
         """rt_stats as a dict: launch counters, and the ray counters of RT_FLAG_COUNT_RAYS launches."""
         st = L.rt_stats()
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+        return {n: (int(getattr(st, n)) if not n.startswith("bounce_") else [int(v) for v in getattr(st, n)]) for n, _ in st._fields_}
 
     def reset_stats(self):
         self._check(self._lib.rt_reset_stats(self._ctx))

@@ -36,3 +36,6 @@ for lights in ("all", "none"):
         print(f"{a.workload} lights={lights} depth={depth}: {ms:.4f} ms (+{ms - prev:.4f})  closest {st['closest_queries']/w/h:.3f}/px "
               f"shadow traced {st['shadow_traced']/w/h:.3f}/px skipped {st['shadow_skipped']/w/h:.3f}/px hits {st['hits']/w/h:.3f}/px", flush=True)
         prev = ms
+
+st = r.stats()
+print("lane utilisation per bounce (last configuration):", " ".join(f"b{b}:{st['bounce_lanes'][b] / max(64 * st['bounce_waves'][b], 1):.3f}({st['bounce_waves'][b]})" for b in range(wl["depth"] + 1)))

@@ -25,6 +25,10 @@ for step in "$@"; do
     trace_c5) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 30 --trace-warmup 3 --no-pmc || exit 1 ;;
     trace_c5spp4) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --no-pmc || exit 1 ;;
     hostpath) timeout -k 10 300 python tools/host_path_rate.py > $OUT/hostpath.log 2>&1 || exit 1; cat $OUT/hostpath.log ;;
+    ab4)      timeout -k 10 300 python tools/ab_bench.py python-ray-tracer_amd/libmi355rt.so python-ray-tracer_amd/libmi355rt.so:64 --workload c4_3840x2160_s64_d5 --rounds 8 --launches 10 > $OUT/ab4.log 2>&1 || exit 1; cat $OUT/ab4.log ;;
+    ab5)      timeout -k 10 400 python tools/ab_bench.py python-ray-tracer_amd/libmi355rt.so python-ray-tracer_amd/libmi355rt.so:64 --workload c5_7680x4320_s256_d8 --rounds 5 --launches 3 > $OUT/ab5.log 2>&1 || exit 1; cat $OUT/ab5.log ;;
+    bdebug)   timeout -k 10 300 python tools/bundle_debug.py > $OUT/bdebug.log 2>&1; cat $OUT/bdebug.log ;;
+    bdebug5)  timeout -k 10 300 python tools/bundle_debug.py --workload c5_7680x4320_s256_d8 --scale 8 > $OUT/bdebug5.log 2>&1; cat $OUT/bdebug5.log ;;
     balance)  timeout -k 10 400 python tools/slab_balance.py > $OUT/balance.log 2>&1 || exit 1; cat $OUT/balance.log ;;
     aa)       timeout -k 10 200 python examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/aa.log 2>&1 || exit 1; cat $OUT/aa.log ;;
     fuzz)     timeout -k 10 400 python tools/fuzz_parity.py --seconds 240 --seed ${FUZZ_SEED:-201} > $OUT/fuzz.log 2>&1; rc=$?; tail -3 $OUT/fuzz.log; [ $rc -ne 0 ] && exit $rc ;;
