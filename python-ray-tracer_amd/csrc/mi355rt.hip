@@ -38,6 +38,8 @@ struct rt_ctx {
     hipEvent_t chunk_ev[RT_RENDER_CHUNKS] = {};
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
     int chunk_mode = -1;              // -1 = by destination memory type
+    int bnd_min_spheres = rt::BND_MIN_SPHERES;   // (MI355RT_BND_MINS overrides)
+    int bnd_max_spheres = 96;         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
@@ -148,12 +150,13 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     return RT_OK;
 }
 
-// instantiations with the bundle pre-cull (scenes with rt::BND_MIN_SPHERES spheres or more; workgroups of 4 only)
-const void *bundle_variant(bool aa, bool park, bool lattice)
+// instantiations with the bundle pre-cull (MODE 1: flat scenes with rt::BND_MIN_SPHERES spheres or more) and with the
+// lane-owned traversal (MODE 2: clustered scenes); workgroups of 4 only
+template <int MODE> const void *mode_variant(bool aa, bool park, bool lattice)
 {
-    if (lattice) return park ? (const void *)rt::render_kernel<false, true, 4, false, true, true> : (const void *)rt::render_kernel<false, false, 4, false, true, true>;
-    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4, false, false, true> : (const void *)rt::render_kernel<true, false, 4, false, false, true>)
-              : (park ? (const void *)rt::render_kernel<false, true, 4, false, false, true> : (const void *)rt::render_kernel<false, false, 4, false, false, true>);
+    if (lattice) return park ? (const void *)rt::render_kernel<false, true, 4, false, true, MODE> : (const void *)rt::render_kernel<false, false, 4, false, true, MODE>;
+    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4, false, false, MODE> : (const void *)rt::render_kernel<true, false, 4, false, false, MODE>)
+              : (park ? (const void *)rt::render_kernel<false, true, 4, false, false, MODE> : (const void *)rt::render_kernel<false, false, 4, false, false, MODE>);
 }
 
 const void *lattice_variant(bool park, int wpw, bool count = false)     // the plain kernel over the half-pixel lattice (RT_AA_REFERENCE)
@@ -335,13 +338,15 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // bundle pre-cull (rt_device.h): scenes with enough spheres for a lane-per-sphere pass to pay; not with the counters
     // (clustered scenes, S > rt::CLUSTER_MIN: measured slower with it — config 5: 22.8 against 20.6 ms; their deep, incoherent
     // bounces dominate and gain nothing from a bundle bound)
-    const bool bnd = ctx->S >= rt::BND_MIN_SPHERES && ctx->NC == 0 && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
+    const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
+    const bool lanes = ctx->NC > 0 && !count && !(p->flags & RT_FLAG_NO_BUNDLES);     // clustered scene: lane-owned traversal (rt_device.h)
     const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bnd);
-    const bool park = !count && lds_park * (24 / wpw) <= 160 * 1024;
+    const bool park = !count && !lanes && lds_park * (24 / wpw) <= 160 * 1024;
     const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bnd);
-    const void *fn = bnd ? bundle_variant(aa, park, lattice) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
+    const void *fn = bnd ? mode_variant<1>(aa, park, lattice) : lanes ? mode_variant<2>(aa, park, lattice)
+                         : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -350,8 +355,10 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         for (int v = 0; v < 4; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(v & 1, (v & 2) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (int v = 0; v < 6; ++v)
-            RT_HIP(ctx, hipFuncSetAttribute(bundle_variant(v & 1, v & 2, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 6; ++v) {
+            RT_HIP(ctx, hipFuncSetAttribute(mode_variant<1>(v & 1, v & 2, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RT_HIP(ctx, hipFuncSetAttribute(mode_variant<2>(v & 1, v & 2, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         ctx->lds_limit_set = lds;
     }
     if (count) {
@@ -369,7 +376,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
-    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (bnd ? 16 : 0);
+    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (bnd ? 16 : 0) + (lanes ? 32 : 0);
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
     if (!fsel) {                                               // a free slot, else the least recently used geometry
@@ -484,6 +491,8 @@ int rt_create(rt_ctx **out, int device)
     rt_ctx *ctx = new (std::nothrow) rt_ctx;
     if (!ctx) return fail(nullptr, RT_ERR_ALLOC, "out of host memory");
     ctx->device = device;
+    if (const char *e = std::getenv("MI355RT_BND_MINS")) ctx->bnd_min_spheres = std::atoi(e);
+    if (const char *e = std::getenv("MI355RT_BND_MAXS")) ctx->bnd_max_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
     hipError_t s;

@@ -44,6 +44,9 @@
 #ifndef RT_FAST_NORMALIZE
 #define RT_FAST_NORMALIZE 1
 #endif
+#ifndef RT_LAZY_RENORM
+#define RT_LAZY_RENORM 0
+#endif
 
 namespace rt {
 
@@ -666,13 +669,197 @@ __device__ __forceinline__ void plane_den_num(const double *__restrict__ g, int 
     }
 }
 
+// intersections.py:6-38 for one sphere record g (float64), on the quadratic divided by 4 (see above), feeding the
+// closest-hit selection: bestn = numerator of the current winner, bidx its slot, borig its caller's index.
+__device__ __forceinline__ void sphere_closest(const double *g, int k, const V3 &o, const V3 &R, double a,
+                                               double &bestn, int &bidx, double &borig)
+{
+    const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};         // :16
+    const double s = dot3(Lv, R);                             // b/2
+    const double cc = dot3(Lv, Lv) - g[3];                    // :21 (g[3] = float32 r*r, widened)
+    const double D = s * s - a * cc;                          // disc/4
+    if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
+        const double q = __builtin_sqrt(D);
+        double n = -s - q;                                    // :28
+        if (!(n > 0.0)) n = -s + q;                           // :33
+        // The reference compares the rounded quotients t = n/a with a strict `best > t`, in ascending caller
+        // index (trace.py:26): the smallest t wins and, among equal t, the lowest index.  Division by the
+        // common a > 0 and rounding are monotone, so numerators order the quotients — except that two
+        // numerators within a couple of ulp of each other may round to the SAME quotient, where the index
+        // decides.  Numerators further apart than a relative 2^-50 have different quotients in the same
+        // order (the gap is four ulp); for closer ones (equal included) both quotients are formed and the
+        // reference's rule is applied literally.  Wave-uniform branch, practically never taken.
+        // Slots are visited in any order (clustered scenes permute them): g[7] is the caller's index.
+        if (n > 0.0) {
+            bool take = n < bestn;
+            const bool close = __builtin_fabs(n - bestn) < bestn * 0x1p-50;   // false while bestn = +inf
+            if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+                if (close) {
+                    const double tq = n / a, tb = bestn / a;                  // :31 / :36
+                    take = tq < tb || (tq == tb && g[7] < borig);
+                }
+            }
+            if (take) { bestn = n; bidx = k; borig = g[7]; }
+        }
+    }
+}
+
+// the same sphere for a shadow (any-hit) query: does it report 0 < t < 999?
+__device__ __forceinline__ bool sphere_any(const double *g, const V3 &o, const V3 &R, double a, bool a_sane)
+{
+    const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};
+    const double s = dot3(Lv, R);
+    const double cc = dot3(Lv, Lv) - g[3];
+    const double D = s * s - a * cc;
+    if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
+        // s < 0: the larger numerator n2 = -s + q is positive, so a positive root exists and
+        // the reference's t is at most n2/a.  n2 <= 998 (from -s < 499, q <= 499) and a within
+        // 1e-6 of 1 give t < 999: occluded, decided without sqrt or divide.
+        if (s < 0.0 && -s < 499.0 && D < 249001.0 && a_sane) return true;
+        const double q = __builtin_sqrt(D);                   // origin inside the sphere, or a far hit: exact path
+        double n = -s - q;
+        if (!(n > 0.0)) n = -s + q;
+        if (n > 0.0) {
+            const double t = n / a;
+            if (999.0 > t && t > 0.0) return true;
+        }
+    }
+    return false;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Lane-owned traversal of clustered scenes (more than CLUSTER_MIN spheres; the LANES instantiations).
+// The wave-uniform cull above opens a cluster for the WHOLE wave as soon as one lane's ray might reach it, and gives
+// every sphere of an opened cluster its per-ray float32 test and — if one lane lacks a certificate — its float64
+// test for all lanes.  That is the right trade while the 64 rays travel together (primary rays, first shadow rays).
+// After a few bounces they do not: every lane's ray opens its own 2-4 clusters, the union over the wave approaches
+// ALL of them, and a wave with 20 rays left pays for hundreds of sphere tests none of its rays needs (measured on
+// config 5: 3x the instructions per wave at bounce 8 compared with bounce 2).
+// Here each lane keeps its own candidates: phase 1 tests the cluster bounds in a wave-uniform loop as before but
+// leaves one bit per cluster IN THE LANE; then the wave loops while any lane has a cluster left, every lane taking
+// ITS next cluster (per-lane LDS addresses: each lane reads the table entries and records of its own spheres),
+// running the 8 float32 tests into a per-lane survivor mask, and looping again over its own survivors for the
+// float64 test.  Iterations = the MAXIMUM over the lanes of their own counts, not the size of the union.
+// Same certificates, same float64 arithmetic, same tie rule (explicit caller's index), any visiting order.
+// ---------------------------------------------------------------------------------------------
+template <bool ANCH>
+__device__ __forceinline__ bool lane_open(const f4 e, const RayF &q)          // true = this lane holds NO certificate
+{
+    if constexpr (ANCH) {
+        const float sd = __builtin_fmaf(e[2], q.R.z, __builtin_fmaf(e[1], q.R.y, e[0] * q.R.x));
+        return !(__builtin_fabsf(sd) < e[3]);                                 // cull_anchored()
+    } else return !cull_origin(e, q);
+}
+__device__ __forceinline__ lds_cf4 *lds_f4(const float *generic)             // per-lane LDS address of a table entry
+{
+    return (lds_cf4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const float *)generic;
+}
+
+// One bit per cluster bound of the block [cb, cb + nc), nc <= 32: set where THIS lane's ray lacks a certificate.
+template <bool ANCH>
+__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q)
+{
+    const int NCp = pad4(lds.NC);
+    lds_cf4 *base = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + cb) * CULL_STRIDE : lds.csph32 + 4 * cb);
+    unsigned cm = 0u;
+    for (int c = 0; c < nc; c += 4) {                                         // tables are padded to a multiple of 4
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("" ::: "memory");
+            const f4 e = base[c + u];
+            cm |= lane_open<ANCH>(e, q) ? (1u << (c + u)) : 0u;
+        }
+    }
+    return cm & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                         // (a NaN ray opens the padding too)
+}
+
+// the survivors among the (up to 8) spheres of the lane's own cluster, first slot kb
+template <bool ANCH>
+__device__ __forceinline__ unsigned lane_sphere_bits(const Lds &lds, int S, int anchor, int kb, const RayF &q)
+{
+    const int Sp = padS(S, lds.NC);
+    lds_cf4 *sb = lds_f4(ANCH ? lds.tab + ((size_t)anchor * Sp + kb) * CULL_STRIDE : lds.sph32 + 4 * kb);
+    unsigned sm = 0u;
+#pragma unroll
+    for (int j = 0; j < CLUSTER; ++j) sm |= lane_open<ANCH>(sb[j], q) ? (1u << j) : 0u;
+    const int nv = S - kb;                                                    // slots past the last sphere are padding
+    return nv >= CLUSTER ? sm : (sm & ((1u << nv) - 1u));
+}
+
+template <bool ANCH>
+__device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a,
+                                              double &bestn, int &bidx, double &borig)
+{
+    RayF q = make_rayf_dir(R);
+    if constexpr (!ANCH) add_origin(q, o, p.extent2);
+    for (int cb = 0; cb < lds.NC; cb += 32) {
+        const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+        while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
+            if (cm != 0u) {
+                const int kb = (cb + __builtin_ctz(cm)) * CLUSTER;
+                cm &= cm - 1u;
+                unsigned sm = lane_sphere_bits<ANCH>(lds, p.S, anchor, kb, q);
+                while (__builtin_amdgcn_ballot_w64(sm != 0u) != 0ull) {
+                    if (sm != 0u) {
+                        const int k = kb + __builtin_ctz(sm);
+                        sm &= sm - 1u;
+                        sphere_closest(lds.rec + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// any-hit: self = the sphere slot this lane's shadow ray starts on (-1: none); its own miss is certified by the
+// origin form's "behind" test where that holds (as in cull_mask)
+template <bool ANCH>
+__device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a, int self)
+{
+    const bool a_sane = (a > 0.999999 && a < 1.000001);
+    RayF q = make_rayf_dir(R);
+    bool self_culled = false;
+    if constexpr (ANCH) {
+        if (__builtin_amdgcn_ballot_w64(self >= 0) != 0ull) {
+            add_origin(q, o, p.extent2);
+            if (self >= 0) { const float *cs = lds.sph32 + 4 * self; self_culled = cull_origin(f4{cs[0], cs[1], cs[2], cs[3]}, q); }
+        }
+    } else add_origin(q, o, p.extent2);
+    bool occ = false;
+    for (int cb = 0; cb < lds.NC; cb += 32) {
+        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
+        const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+        if (occ) cm = 0u;
+        while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
+            if (cm != 0u) {
+                const int kb = (cb + __builtin_ctz(cm)) * CLUSTER;
+                cm &= cm - 1u;
+                unsigned sm = lane_sphere_bits<ANCH>(lds, p.S, anchor, kb, q);
+                if (self_culled && self >= kb && self < kb + CLUSTER) sm &= ~(1u << (self - kb));
+                while (__builtin_amdgcn_ballot_w64(sm != 0u) != 0ull) {
+                    if (sm != 0u) {
+                        const int k = kb + __builtin_ctz(sm);
+                        sm &= sm - 1u;
+                        if (sphere_any(lds.rec + k * SPH_STRIDE, o, R, a, a_sane)) { occ = true; sm = 0u; cm = 0u; }
+                    }
+                }
+            }
+        }
+    }
+    return occ;
+}
+
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
-template <bool BND>
+template <int MODE>      // 0: wave-uniform cull; 1: + bundle pre-cull (cand); 2: lane-owned traversal of a clustered scene
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
                                             double &t_out, int &idx_out, int &type_out, const Cand &cand)
 {
+    constexpr bool BND = MODE == 1;
     const int P = p.P;
     // the bundle pre-cull left no sphere any lane's ray could reach: the sphere part — including the re-normalised
     // direction only it uses — is skipped (wave-uniform)
@@ -685,6 +872,10 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #endif
     double bestn = __builtin_inf(), borig = 0.0;
     int bidx = -1;
+    if (MODE == 2 && lds.NC > 0) {
+        if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig);
+        else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig);
+    } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
@@ -698,35 +889,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
       while (mask) {                                          // spheres some live lane might hit, ascending
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        const double *g = lds.rec + k * SPH_STRIDE;
-        const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};     // :16
-        const double s = dot3(Lv, R);                         // b/2
-        const double cc = dot3(Lv, Lv) - g[3];                // :21 (g[3] = float32 r*r, widened)
-        const double D = s * s - a * cc;                      // disc/4
-        if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
-            const double q = __builtin_sqrt(D);
-            double n = -s - q;                                // :28
-            if (!(n > 0.0)) n = -s + q;                       // :33
-            // The reference compares the rounded quotients t = n/a with a strict `best > t`, in ascending caller
-            // index (trace.py:26): the smallest t wins and, among equal t, the lowest index.  Division by the
-            // common a > 0 and rounding are monotone, so numerators order the quotients — except that two
-            // numerators within a couple of ulp of each other may round to the SAME quotient, where the index
-            // decides.  Numerators further apart than a relative 2^-50 have different quotients in the same
-            // order (the gap is four ulp); for closer ones (equal included) both quotients are formed and the
-            // reference's rule is applied literally.  Wave-uniform branch, practically never taken.
-            // Slots are visited in slot order, which for clustered scenes is a permutation: g[7] is the caller's index.
-            if (n > 0.0) {
-                bool take = n < bestn;
-                const bool close = __builtin_fabs(n - bestn) < bestn * 0x1p-50;   // false while bestn = +inf
-                if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
-                    if (close) {
-                        const double tq = n / a, tb = bestn / a;                  // :31 / :36
-                        take = tq < tb || (tq == tb && g[7] < borig);
-                    }
-                }
-                if (take) { bestn = n; bidx = k; borig = g[7]; }
-            }
-        }
+        sphere_closest(lds.rec + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
       }
     }
     double best = 999.0;                                      // trace.py:17
@@ -752,56 +915,43 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 // Called with the lanes that need the answer active; returns true if occluded.
 // anchor = cull-table index of the light the ray points at; self = index of the sphere the ray
 // starts on (-1: a plane), whose miss is certified by the origin-form "behind" test.
-template <bool BND>
+template <int MODE>
 __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const Cand &cand)
 {
+    constexpr bool BND = MODE == 1;
     const int P = p.P;
     const int S = (BND && (cand.w0 | cand.w1) == 0ull) ? 0 : p.S;           // no candidate sphere for any lane (wave-uniform)
     V3 R{0.0, 0.0, 0.0};
     double a = 1.0;
-    if (!BND || S > 0) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
-    const bool a_sane = (a > 0.999999 && a < 1.000001);
+    // RT_LAZY_RENORM: the float32 cull runs on d itself (within 2^-52 of R: the same float32 values up to the
+    // rounding the margins already budget for) and R, a are formed only if some lane's mask is not empty
+    constexpr bool LAZY = RT_LAZY_RENORM && MODE == 0;
+    if (!LAZY && (!BND || S > 0)) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
+    bool a_sane = (a > 0.999999 && a < 1.000001);
+    bool haveR = !LAZY;
     bool occ = false;
 #if RT_PREFILTER
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
+    if (MODE == 2 && lds.NC > 0) {
+        occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self) : lanes_any<false>(lds, p, -1, o, R, a, self);
+    } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
-      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, self, cand);
+      mask = cull_mask(lds, S, canchor, k0, n, o, LAZY ? d : R, p.extent2, self, cand);
       mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
+      if (LAZY && mask && !haveR) { R = renormalize_unit(d); a = dot3(R, R); a_sane = (a > 0.999999 && a < 1.000001); haveR = true; }
       while (mask) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        if (!occ) {
-            const double *g = lds.rec + k * SPH_STRIDE;
-            const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};
-            const double s = dot3(Lv, R);
-            const double cc = dot3(Lv, Lv) - g[3];
-            const double D = s * s - a * cc;
-            if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
-                // s < 0: the larger numerator n2 = -s + q is positive, so a positive root exists and
-                // the reference's t is at most n2/a.  n2 <= 998 (from -s < 499, q <= 499) and a within
-                // 1e-6 of 1 give t < 999: occluded, decided without sqrt or divide.
-                if (s < 0.0 && -s < 499.0 && D < 249001.0 && a_sane) {
-                    occ = true;
-                } else {                                      // origin inside the sphere, or a far hit: exact path
-                    const double q = __builtin_sqrt(D);
-                    double n = -s - q;
-                    if (!(n > 0.0)) n = -s + q;
-                    if (n > 0.0) {
-                        const double t = n / a;
-                        if (999.0 > t && t > 0.0) occ = true;
-                    }
-                }
-            }
-        }
+        if (!occ) occ = sphere_any(lds.rec + k * SPH_STRIDE, o, R, a, a_sane);
       }
     }
     const double *pl = lds.rec + p.S * SPH_STRIDE;
@@ -842,7 +992,7 @@ template <> struct RayCount<true> {
 
 // trace.py:44-112.  On entry `alive` lanes carry a ray (o,d); on exit `alive` is false for lanes
 // that missed (the reference's 404 sentinels), rgb is this bounce's colour, (o,d) the next ray.
-template <bool PARK, int WGT, bool COUNT>
+template <bool PARK, int WGT, bool COUNT, bool LANES>
 __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                              V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt)
 {
@@ -850,7 +1000,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
-    if (alive) closest_hit<false>(lds, p, o, d, anchor, t, idx, type, Cand{0ull, 0ull, false});   // :53 (idle lanes masked off)
+    if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type, Cand{0ull, 0ull, false});   // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
     if (alive) {
@@ -887,7 +1037,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             // so lanes with k <= 0 (light behind the surface) do not ask.
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
-                const bool occluded = any_hit<false>(lds, p, Pt, Ld, 1 + m, self, Cand{0ull, 0ull, false});
+                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, Cand{0ull, 0ull, false});
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -919,7 +1069,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     cnt.closest(alive);
     {
         const Cand cc{bnd_load(lds, 0), bnd_load(lds, 1), true};
-        if (alive) closest_hit<true>(lds, p, o, d, anchor, t, idx, type, cc);       // :53
+        if (alive) closest_hit<1>(lds, p, o, d, anchor, t, idx, type, cc);       // :53
     }
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
@@ -969,7 +1119,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
                 const Cand cs = m < nl ? Cand{bnd_load(lds, 2 + 2 * m), bnd_load(lds, 3 + 2 * m), true} : Cand{~0ull, ~0ull, false};
-                const bool occluded = any_hit<true>(lds, p, Pt, Ld, 1 + m, self, cs);
+                const bool occluded = any_hit<1>(lds, p, Pt, Ld, 1 + m, self, cs);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -1003,9 +1153,10 @@ __device__ __forceinline__ void primary_bundle(const Lds &lds, const KParams &p,
 }
 
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
-template <bool PARK, int WGT, bool COUNT, bool BND>
+template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 1 bundle pre-cull, 2 lane-owned traversal
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
+    constexpr bool BND = MODE == 1;
     Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
     if constexpr (BND) primary_bundle(lds, p, alive, d);
@@ -1021,7 +1172,7 @@ __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool aliv
         V3 rgb;
         if constexpr (BND) trace_bounce_bnd<PARK, WGT, COUNT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt, b == p.depth);
         else
-        trace_bounce<PARK, WGT, COUNT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
+        trace_bounce<PARK, WGT, COUNT, MODE == 2>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
             const double wgt = p.refl_pow[b - 1];
@@ -1184,7 +1335,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
 // live state (registers decide occupancy here).
-template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, bool BND = false>
+template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, int MODE = 0>
 #ifndef RT_W_PARK
 #define RT_W_PARK 7
 #endif
@@ -1194,7 +1345,10 @@ template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, boo
 #ifndef RT_W_BND
 #define RT_W_BND 6      // the bundle variants keep a few more values live between the divergent parts
 #endif
-__global__ __launch_bounds__(64 * WPW, (BND && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
+#ifndef RT_W_LANES
+#define RT_W_LANES 4    // lane-owned traversal (clustered scenes: the LDS image bounds the occupancy at about 4 anyway) wants registers
+#endif
+__global__ __launch_bounds__(64 * WPW, MODE == 2 ? RT_W_LANES : (MODE == 1 && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
     extern __shared__ double lds_raw[];
@@ -1247,7 +1401,7 @@ __global__ __launch_bounds__(64 * WPW, (BND && PARK) ? RT_W_BND : (AA ? (PARK ? 
     RayCount<COUNT> cnt;
     double R, G, B;
     if constexpr (!AA) {
-        const V3 c = sample<PARK, WG_THREADS, COUNT, BND>(lds, p, inb, o, primary_dir(p, LAT ? lattice_P(p, xc, yc) : pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
+        const V3 c = sample<PARK, WG_THREADS, COUNT, MODE>(lds, p, inb, o, primary_dir(p, LAT ? lattice_P(p, xc, yc) : pixel_P(p, xc, yc)), cnt);   // kernels.py:19-26
         R = c.x; G = c.y; B = c.z;
     } else {
         // kernels.py:26-65 as ONE loop: tap 0 is the centre sample, taps 1-8 the half-pixel neighbours (only
@@ -1275,7 +1429,7 @@ __global__ __launch_bounds__(64 * WPW, (BND && PARK) ? RT_W_BND : (AA ? (PARK ? 
                 const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
                 Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // :43-50
             }
-            const V3 s = sample<PARK, WG_THREADS, COUNT, BND>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt), cnt);   // :26 / :56
+            const V3 s = sample<PARK, WG_THREADS, COUNT, MODE>(lds, p, (tap && !stoch) ? interior : inb, o, primary_dir(p, Pt), cnt);   // :26 / :56
             if (tap == 0) taps.set(s);
             else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.y, a.z + s.z}); }
             else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + s.x, a.y + s.z, a.z + s.y}); }   // :58-60 (G += B_s; B += G_s)
