@@ -342,9 +342,12 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool lanes = ctx->NC > 0 && !count && !(p->flags & RT_FLAG_NO_BUNDLES);     // clustered scene: lane-owned traversal (rt_device.h)
     const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
-    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bnd);
+    const bool bwords = bnd;                                                        // the waves' bundle words in LDS
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bwords);
     const bool park = !count && !lanes && lds_park * (24 / wpw) <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bnd);
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bwords);
+    // (bundle candidates in front of the lane-owned traversal — MODE 3 in rt_device.h — measured slower on config 5:
+    // 22.0 against 19.2 ms; the passes cost more at the deep, incoherent bounces than they save at the first two)
     const void *fn = bnd ? mode_variant<1>(aa, park, lattice) : lanes ? mode_variant<2>(aa, park, lattice)
                          : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {

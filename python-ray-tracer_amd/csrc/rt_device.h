@@ -757,13 +757,16 @@ __device__ __forceinline__ lds_cf4 *lds_f4(const float *generic)             // 
 }
 
 // One bit per cluster bound of the block [cb, cb + nc), nc <= 32: set where THIS lane's ray lacks a certificate.
+// cand: the bundle pre-cull's candidate clusters of this block (all ones without it) — a wave-uniform word; groups of 4
+// bounds without a candidate are skipped.
 template <bool ANCH>
-__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q)
+__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q, unsigned cand)
 {
     const int NCp = pad4(lds.NC);
     lds_cf4 *base = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + cb) * CULL_STRIDE : lds.csph32 + 4 * cb);
     unsigned cm = 0u;
     for (int c = 0; c < nc; c += 4) {                                         // tables are padded to a multiple of 4
+        if (((cand >> c) & 0xFu) == 0u) continue;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             asm volatile("" ::: "memory");
@@ -771,7 +774,7 @@ __device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor
             cm |= lane_open<ANCH>(e, q) ? (1u << (c + u)) : 0u;
         }
     }
-    return cm & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                         // (a NaN ray opens the padding too)
+    return cm & cand & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                  // (a NaN ray opens the padding too)
 }
 
 // the survivors among the (up to 8) spheres of the lane's own cluster, first slot kb
@@ -787,15 +790,20 @@ __device__ __forceinline__ unsigned lane_sphere_bits(const Lds &lds, int S, int 
     return nv >= CLUSTER ? sm : (sm & ((1u << nv) - 1u));
 }
 
+__device__ __forceinline__ unsigned cand_block(const Cand &cand, int cb)     // the 32 candidate bits of cluster block cb
+{
+    return cand.on ? (unsigned)((cb < 64 ? cand.w0 : cand.w1) >> (cb & 63)) : ~0u;
+}
+
 template <bool ANCH>
 __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a,
-                                              double &bestn, int &bidx, double &borig)
+                                              double &bestn, int &bidx, double &borig, const Cand &cand)
 {
     RayF q = make_rayf_dir(R);
     if constexpr (!ANCH) add_origin(q, o, p.extent2);
     for (int cb = 0; cb < lds.NC; cb += 32) {
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
-        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, cand_block(cand, cb));
         while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
             if (cm != 0u) {
                 const int kb = (cb + __builtin_ctz(cm)) * CLUSTER;
@@ -816,7 +824,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
 // any-hit: self = the sphere slot this lane's shadow ray starts on (-1: none); its own miss is certified by the
 // origin form's "behind" test where that holds (as in cull_mask)
 template <bool ANCH>
-__device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a, int self)
+__device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a, int self, const Cand &cand)
 {
     const bool a_sane = (a > 0.999999 && a < 1.000001);
     RayF q = make_rayf_dir(R);
@@ -831,7 +839,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
     for (int cb = 0; cb < lds.NC; cb += 32) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
-        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, cand_block(cand, cb));
         if (occ) cm = 0u;
         while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
             if (cm != 0u) {
@@ -855,11 +863,11 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
-template <int MODE>      // 0: wave-uniform cull; 1: + bundle pre-cull (cand); 2: lane-owned traversal of a clustered scene
+template <int MODE>      // 0: wave-uniform cull; 1: + bundle pre-cull (cand); 2: lane-owned traversal of a clustered scene; 3: 2 with the pre-cull's candidate clusters
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
                                             double &t_out, int &idx_out, int &type_out, const Cand &cand)
 {
-    constexpr bool BND = MODE == 1;
+    constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = p.P;
     // the bundle pre-cull left no sphere any lane's ray could reach: the sphere part — including the re-normalised
     // direction only it uses — is skipped (wave-uniform)
@@ -872,9 +880,11 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #endif
     double bestn = __builtin_inf(), borig = 0.0;
     int bidx = -1;
-    if (MODE == 2 && lds.NC > 0) {
-        if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig);
-        else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig);
+    if (MODE >= 2 && lds.NC > 0) {
+        if (S > 0) {
+            if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig, cand);
+            else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig, cand);
+        }
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
@@ -918,7 +928,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 template <int MODE>
 __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const Cand &cand)
 {
-    constexpr bool BND = MODE == 1;
+    constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = p.P;
     const int S = (BND && (cand.w0 | cand.w1) == 0ull) ? 0 : p.S;           // no candidate sphere for any lane (wave-uniform)
     V3 R{0.0, 0.0, 0.0};
@@ -933,8 +943,8 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
 #if RT_PREFILTER
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
-    if (MODE == 2 && lds.NC > 0) {
-        occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self) : lanes_any<false>(lds, p, -1, o, R, a, self);
+    if (MODE >= 2 && lds.NC > 0) {
+        if (S > 0) occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self, cand) : lanes_any<false>(lds, p, -1, o, R, a, self, cand);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
@@ -1059,7 +1069,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 //   | ball of the hit points -> one candidate pass per light       — whole wave
 //   | light loop, reflection                   — lanes that hit
 //   | cone of the reflected directions -> candidates of the next closest-hit query      — whole wave
-template <bool PARK, int WGT, bool COUNT>
+template <bool PARK, int WGT, bool COUNT, int MODE>
 __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                                  V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt, bool last)
 {
@@ -1069,7 +1079,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     cnt.closest(alive);
     {
         const Cand cc{bnd_load(lds, 0), bnd_load(lds, 1), true};
-        if (alive) closest_hit<1>(lds, p, o, d, anchor, t, idx, type, cc);       // :53
+        if (alive) closest_hit<MODE>(lds, p, o, d, anchor, t, idx, type, cc);    // :53
     }
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
@@ -1119,7 +1129,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
                 const Cand cs = m < nl ? Cand{bnd_load(lds, 2 + 2 * m), bnd_load(lds, 3 + 2 * m), true} : Cand{~0ull, ~0ull, false};
-                const bool occluded = any_hit<1>(lds, p, Pt, Ld, 1 + m, self, cs);
+                const bool occluded = any_hit<MODE>(lds, p, Pt, Ld, 1 + m, self, cs);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -1156,7 +1166,7 @@ __device__ __forceinline__ void primary_bundle(const Lds &lds, const KParams &p,
 template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 1 bundle pre-cull, 2 lane-owned traversal
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
-    constexpr bool BND = MODE == 1;
+    constexpr bool BND = MODE == 1 || MODE == 3;
     Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
     if constexpr (BND) primary_bundle(lds, p, alive, d);
@@ -1170,7 +1180,7 @@ __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool aliv
             }
         }
         V3 rgb;
-        if constexpr (BND) trace_bounce_bnd<PARK, WGT, COUNT>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt, b == p.depth);
+        if constexpr (BND) trace_bounce_bnd<PARK, WGT, COUNT, MODE>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt, b == p.depth);
         else
         trace_bounce<PARK, WGT, COUNT, MODE == 2>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
@@ -1348,7 +1358,7 @@ template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, int
 #ifndef RT_W_LANES
 #define RT_W_LANES 4    // lane-owned traversal (clustered scenes: the LDS image bounds the occupancy at about 4 anyway) wants registers
 #endif
-__global__ __launch_bounds__(64 * WPW, MODE == 2 ? RT_W_LANES : (MODE == 1 && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
+__global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
     extern __shared__ double lds_raw[];
