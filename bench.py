@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-serial", action="store_true", help="skip the one-stream pass behind the timed region (roofline.serial)")
     ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point rt_render (host_path_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for every launch (e.g. 4 = RT_FLAG_NO_FEEDBACK; profiling variants)")
     ap.add_argument("--balance-rounds", type=int, default=4, help="N > 1: rounds of measured-time slab balancing before the run (0 = equal-width slabs)")
     a = ap.parse_args()
 
@@ -125,7 +126,8 @@ def main():
     r.set_scene(wl["spheres"], wl["lights"], wl["planes"])
     r.set_camera(cam.position, cam.rotation)
     r.set_raygen(w, h, *cam.raygen())
-    params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"])
+    params = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"], flags=a.flags)
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:

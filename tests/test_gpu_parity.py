@@ -685,3 +685,37 @@ def test_renderer_example_writes_png(tmp_path):
     from PIL import Image
     im = np.asarray(Image.open(out))
     assert im.shape == (96, 160, 3) and im.any()
+
+
+def test_many_launch_geometries_share_the_feedback_slots(renderer):
+    """The context keeps the dispatch-order feedback of 8 launch geometries; 11 different column ranges, each launched
+    three times in rotation (so every slot is evicted and re-measured), must all produce their part of the frame."""
+    g = load_frame("default_128_d3")
+    w, h, _ = _setup(renderer, g)
+    full8, _ = _render(renderer, g)
+    ranges = [(8 * i, 8 * i + 40) for i in range(11)]
+    before = renderer.stats()
+    for rep in range(3):
+        for a, b in ranges:
+            part8, _ = _render(renderer, g, x0=a, x1=b)
+            assert np.array_equal(part8, full8[:, a:b]), (rep, a, b)
+    st = renderer.stats()
+    assert st["launches"] - before["launches"] == 33 and st["launches_measuring"] - before["launches_measuring"] >= 22
+
+
+def test_stream_forget(renderer):
+    """A caller-owned stream (here one made by the library, standing in for a torch stream) can be forgotten and used again."""
+    g = load_frame("c1_128")
+    w, h, _ = _setup(renderer, g)
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+    s_ = renderer.stream_create()
+    d8 = renderer.malloc(3 * w * h)
+    try:
+        for rep in range(3):
+            for _ in range(4):
+                renderer.render_device(p, 0, w, d8, None, w * h, stream=s_)
+            renderer.stream_forget(s_)                     # waits for the stream, drops the context's references
+            got = np.empty((3, w, h), np.uint8); renderer.d2h(got, d8)
+            assert np.array_equal(got, g["frame_u8"])
+    finally:
+        renderer.stream_destroy(s_); renderer.free(d8)

@@ -30,6 +30,7 @@ for step in "$@"; do
     bdebug)   timeout -k 10 300 python tools/bundle_debug.py > $OUT/bdebug.log 2>&1; cat $OUT/bdebug.log ;;
     bdebug5)  timeout -k 10 300 python tools/bundle_debug.py --workload c5_7680x4320_s256_d8 --scale 8 > $OUT/bdebug5.log 2>&1; cat $OUT/bdebug5.log ;;
     balance)  timeout -k 10 400 python tools/slab_balance.py > $OUT/balance.log 2>&1 || exit 1; cat $OUT/balance.log ;;
+    trace_aa) mkdir -p $OUT/trace_aa && cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_aa -- python3 $ROOT/examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/trace_aa.log 2>&1 || exit 1; cd $ROOT; cp $(find $OUT/trace_aa -name "*kernel_stats.csv" | head -1) $OUT/aa_kernel_stats.csv; rm -rf $OUT/trace_aa; tail -1 $OUT/trace_aa.log; head -4 $OUT/aa_kernel_stats.csv ;;
     aa)       timeout -k 10 200 python examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/aa.log 2>&1 || exit 1; cat $OUT/aa.log ;;
     fuzz)     timeout -k 10 400 python tools/fuzz_parity.py --seconds 240 --seed ${FUZZ_SEED:-201} > $OUT/fuzz.log 2>&1; rc=$?; tail -3 $OUT/fuzz.log; [ $rc -ne 0 ] && exit $rc ;;
     *) echo "unknown step $step"; exit 2 ;;

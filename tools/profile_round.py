@@ -61,12 +61,13 @@ def main():
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--stamp", action="store_true")
     ap.add_argument("--round", default="r02")
+    ap.add_argument("--flags", type=int, default=0)
     a = ap.parse_args()
     out = os.path.join(REPO, "gpurun_out", f"prof_{a.tag}")
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
     bench = os.path.join(REPO, "bench.py")
-    common = ["--streams", str(a.streams), "--no-cpu-baseline"] + (["--workload", a.workload] if a.workload else [])
+    common = ["--streams", str(a.streams), "--no-cpu-baseline"] + (["--workload", a.workload] if a.workload else []) + (["--flags", str(a.flags)] if a.flags else [])
 
     # 1. kernel trace of the bench command (full bench line, incl. the serial pass and the host path)
     tdir = os.path.join(out, "trace")
