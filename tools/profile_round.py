@@ -69,10 +69,12 @@ def main():
     bench = os.path.join(REPO, "bench.py")
     common = ["--streams", str(a.streams), "--no-cpu-baseline"] + (["--workload", a.workload] if a.workload else []) + (["--flags", str(a.flags)] if a.flags else [])
 
-    # 1. kernel trace of the bench command (full bench line, incl. the serial pass and the host path)
+    # 1. kernel trace of the bench command, without its serial pass and host-path timing: every render launch in the
+    #    trace is then of the kind the timed region times (pre-heat, warm-up and timed steps on --streams streams), so
+    #    the stats' average duration is directly comparable with roofline.kernel_ms of the bench line printed in the run
     tdir = os.path.join(out, "trace")
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tdir, "--", "python3", bench,
-         "--steps", str(a.trace_steps), "--warmup", str(a.trace_warmup)] + common, os.path.join(out, "trace.log"))
+         "--steps", str(a.trace_steps), "--warmup", str(a.trace_warmup), "--no-serial", "--no-host-path"] + common, os.path.join(out, "trace.log"))
     ks = glob.glob(os.path.join(tdir, "**", "*kernel_stats.csv"), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(out, "trace_kernel_stats.csv"))
