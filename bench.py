@@ -384,7 +384,7 @@ def main():
         dist.destroy_process_group()
 
 
-def balance_slabs(r, params, w, h, world, rank, dev, dist, torch, ns, rounds, frames=48):
+def balance_slabs(r, params, w, h, world, rank, dev, dist, torch, ns, rounds, frames=400):
     """Every rank times its own slab (frames round-robin on `ns` streams, as in the run), the times are all-gathered
     and python_ray_tracer_amd.distributed.SlabBalancer moves the boundaries; the last round only measures."""
     from python_ray_tracer_amd.distributed import SlabBalancer
@@ -393,6 +393,10 @@ def balance_slabs(r, params, w, h, world, rank, dev, dist, torch, ns, rounds, fr
     u8 = [torch.empty(3 * w * h, dtype=torch.uint8, device=dev) for _ in range(ns)]
     f32 = [torch.empty(3 * w * h, dtype=torch.float32, device=dev) for _ in range(ns)]
     history = []
+    for i in range(600):                                  # clocks up before anything is compared (about 10-40 ms)
+        a_, b_ = bal.bounds[rank]
+        r.render_device(params, a_, b_, u8[i % ns].data_ptr(), f32[i % ns].data_ptr(), (b_ - a_) * h, streams[i % ns].cuda_stream)
+    torch.cuda.synchronize()
     for it in range(rounds + 1):
         a_, b_ = bal.bounds[rank]
 
