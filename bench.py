@@ -241,9 +241,10 @@ def main():
             last[s_] = evs[i]
             done.append(ev0[0].elapsed_time(evs[i]))     # completion time of step i on a common clock
         # NS launches are in flight together and complete in clumps, so the period of a frame is taken over a window
-        # of NS consecutive completions: (t[i] - t[i - NS]) / NS
+        # of 2 NS consecutive completions: (t[i] - t[i - 2 NS]) / (2 NS)
         done.sort()
-        periods = [(done[i] - done[i - NS]) / NS for i in range(NS, len(done))]
+        W = 2 * NS if len(done) > 2 * NS else NS
+        periods = [(done[i] - done[i - W]) / W for i in range(W, len(done))]
     if not use_gather:
         frame = pipe.last_slab()[:, :ws]
 

@@ -44,6 +44,9 @@
 #ifndef RT_FAST_NORMALIZE
 #define RT_FAST_NORMALIZE 1
 #endif
+#ifndef RT_BND_MAXSIN
+#define RT_BND_MAXSIN 0.5f   // widest bundle (sine of the cone's half-angle) the pre-cull is attempted for
+#endif
 #ifndef RT_LAZY_RENORM
 #define RT_LAZY_RENORM 0
 #endif
@@ -445,7 +448,7 @@ __device__ __forceinline__ Cone direction_cone(bool part, const V3 &d)
     const float s2 = wave_max_nonneg(part ? (dt > 0.0f ? __builtin_fmaf(kz, kz, __builtin_fmaf(ky, ky, kx * kx)) : 1.0f) : 0.0f);
     c.sing = uni(__builtin_fmaf(__builtin_sqrtf(s2), 1.0f + 0x1p-10f, 0x1p-20f));                  // rounded up
     c.cosg = uni(__builtin_sqrtf(__builtin_fmaxf(1.0f - c.sing * c.sing, 0.0f)) * (1.0f - 0x1p-20f));  // rounded down
-    c.ok = (m != 0ull) && (c.sing < 0.5f);                 // directions more than 30 degrees apart: not a bundle
+    c.ok = (m != 0ull) && (c.sing < RT_BND_MAXSIN);         // directions too far apart: not a bundle
     return c;
 }
 
@@ -476,7 +479,7 @@ __device__ __forceinline__ Cone cone_toward(const Ball &b, float ax, float ay, f
     c.x = uni(ux * inv); c.y = uni(uy * inv); c.z = uni(uz * inv);
     c.sing = uni(__builtin_fmaf(b.rho * inv, 1.0f + 0x1p-10f, 0x1p-20f));
     c.cosg = uni(__builtin_sqrtf(__builtin_fmaxf(1.0f - c.sing * c.sing, 0.0f)) * (1.0f - 0x1p-20f));
-    c.ok = b.ok && (c.sing < 0.5f);                         // (NaN fails)
+    c.ok = b.ok && (c.sing < RT_BND_MAXSIN);                // (NaN fails)
     return c;
 }
 
