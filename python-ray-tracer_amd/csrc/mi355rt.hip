@@ -39,7 +39,8 @@ struct rt_ctx {
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
     int chunk_mode = -1;              // -1 = by destination memory type
     int bnd_min_spheres = rt::BND_MIN_SPHERES;   // (MI355RT_BND_MINS overrides)
-    int bnd_max_spheres = 96;         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
+    int bnd_max_spheres = 96;
+    int lanes_primary = 0, lanes_min_spheres = 1 << 30;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
@@ -272,6 +273,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.S = ctx->S; k.P = ctx->P; k.L = ctx->L; k.depth = p->depth; k.NC = ctx->NC; k.plane_codes = ctx->plane_codes;
     k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0; k.u8_hwc = (p->flags & RT_FLAG_U8_HWC) ? 1 : 0;
     k.spp = p->spp; k.seed = p->seed;
+    k.lanes_primary = ctx->lanes_primary;
     k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
     const int tiles_x = (x1 - x0 + rt::TILE - 1) / rt::TILE;
     k.ntiles = tiles_x * k.tiles_y;
@@ -339,7 +341,11 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // (clustered scenes, S > rt::CLUSTER_MIN: measured slower with it — config 5: 22.8 against 20.6 ms; their deep, incoherent
     // bounces dominate and gain nothing from a bundle bound)
     const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    const bool lanes = ctx->NC > 0 && !count && !(p->flags & RT_FLAG_NO_BUNDLES);     // clustered scene: lane-owned traversal (rt_device.h)
+    // Lane-owned traversal wants 128 VGPRs (4 waves/SIMD).  It pays where the scene's LDS image holds the wave-uniform
+    // register variant (5 waves/SIMD) to 4 anyway — 256 spheres: -7..-9 % at depth 5 and 8 — and loses where it costs a wave
+    // (144 spheres, depth 5: +20 %; 196 spheres: +8..+10 %).
+    const bool lds_bound4 = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, k.aa != 0, false, 256) * 5 > 160 * 1024;
+    const bool lanes = ctx->NC > 0 && (lds_bound4 || ctx->S >= ctx->lanes_min_spheres) && !count && !(p->flags & RT_FLAG_NO_BUNDLES);     // clustered scene: lane-owned traversal (rt_device.h)
     const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const bool bwords = bnd;                                                        // the waves' bundle words in LDS
@@ -494,6 +500,8 @@ int rt_create(rt_ctx **out, int device)
     rt_ctx *ctx = new (std::nothrow) rt_ctx;
     if (!ctx) return fail(nullptr, RT_ERR_ALLOC, "out of host memory");
     ctx->device = device;
+    if (const char *e = std::getenv("MI355RT_LANES_PRIMARY")) ctx->lanes_primary = std::atoi(e);
+    if (const char *e = std::getenv("MI355RT_LANES_MINS")) ctx->lanes_min_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_BND_MINS")) ctx->bnd_min_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_BND_MAXS")) ctx->bnd_max_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);

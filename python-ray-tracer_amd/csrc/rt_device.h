@@ -95,6 +95,7 @@ struct KParams {
     int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
     unsigned seed;             // jitter hash seed (stochastic AA)
     int u8_hwc;                // uint8 frame interleaved as [y][x][3] (an image), row pitch = plane_stride pixels
+    int lanes_primary;         // MODE 2: lane-owned traversal for the primary rays and their shadow rays too (else from bounce 1 on)
     float extent2, floor_anch; // max squared distance of camera / lights / sphere surfaces from the world origin;
                                // launch-constant floor of the anchored cull (host: 2^-39 (|cam| + 999(depth+1) + extent)²)
     double px, y0, dy, z0, dz;
@@ -403,7 +404,7 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // All of it runs in wave-uniform control flow with all 64 lanes executing (lanes without a ray contribute neutral
 // values), between the divergent parts of trace_bounce; the masks wait in the wave's LDS words until the queries read them.
 // ---------------------------------------------------------------------------------------------
-constexpr int BND_MIN_SPHERES = 24;      // below this the per-ray cull is cheaper than the passes
+constexpr int BND_MIN_SPHERES = 40;      // below this the per-ray cull is cheaper than the passes (measured: 36 spheres +3 %, 49 spheres -16 %)
 constexpr int BND_LIGHTS = 8;            // lights with their own candidate masks (further lights: no pre-cull)
 constexpr int BND_WORDS = 2 + 2 * BND_LIGHTS + 2;   // closest-hit masks (2), per light (2 each), ball {C.xyz, rho} (2 words)
 struct Cand { unsigned long long w0, w1; bool on; };      // candidates of one query: spheres (flat scene) or clusters; 128 of them at most
@@ -883,7 +884,9 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #endif
     double bestn = __builtin_inf(), borig = 0.0;
     int bidx = -1;
-    if (MODE >= 2 && lds.NC > 0) {
+    // lane-owned traversal for the rays without a common anchor (bounce 1 on), where the wave's rays have parted;
+    // the primary rays of a tile travel together: the wave-uniform cull below is cheaper for them
+    if (MODE >= 2 && lds.NC > 0 && (canchor < 0 || p.lanes_primary)) {
         if (S > 0) {
             if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig, cand);
             else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig, cand);
@@ -929,7 +932,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 // anchor = cull-table index of the light the ray points at; self = index of the sphere the ray
 // starts on (-1: a plane), whose miss is certified by the origin-form "behind" test.
 template <int MODE>
-__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const Cand &cand)
+__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const Cand &cand, bool lanes = true)
 {
     constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = p.P;
@@ -946,7 +949,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
 #if RT_PREFILTER
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
-    if (MODE >= 2 && lds.NC > 0) {
+    if (MODE >= 2 && lds.NC > 0 && lanes) {
         if (S > 0) occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self, cand) : lanes_any<false>(lds, p, -1, o, R, a, self, cand);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
@@ -1050,7 +1053,8 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             // so lanes with k <= 0 (light behind the surface) do not ask.
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
-                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, Cand{0ull, 0ull, false});
+                // (the shadow rays of the primary hits still travel together: wave-uniform cull unless p.lanes_primary)
+                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, Cand{0ull, 0ull, false}, anchor != 0 || p.lanes_primary);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }

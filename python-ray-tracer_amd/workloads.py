@@ -43,6 +43,19 @@ CONFIGS = {
     # BASELINE config 5 proper: 4 stochastic samples per pixel (aa mode 2 = RT_AA_STOCHASTIC, seed 1)
     "c5_7680x4320_s256_d8_spp4": (7680, 4320, 8, 2, lambda: _scene(grid_spheres(16, 356)), None),
 }
+# not BASELINE configurations: scene sizes between them, for choosing the kernel variants' thresholds (tools/ab_bench.py)
+CONFIGS.update({
+    "x_1920x1080_s25_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(5, 360)), None),
+    "x_1920x1080_s36_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(6, 361)), None),
+    "x_1920x1080_s49_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(7, 362)), None),
+    "x_3840x2160_s49_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(7, 362)), None),
+    "x_3840x2160_s36_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(6, 361)), None),
+    "x_7680x4320_s196_d8": (7680, 4320, 8, False, lambda: _scene(grid_spheres(14, 359)), None),
+    "x_3840x2160_s256_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(16, 356)), None),
+    "x_3840x2160_s100_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(10, 357)), None),
+    "x_3840x2160_s144_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(12, 358)), None),
+    "x_1920x1080_s196_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(14, 359)), None),
+})
 STOCHASTIC = {"c5_7680x4320_s256_d8_spp4": dict(spp=4, seed=1)}
 HEADLINE = "c2_1920x1080_s8_d3"
 
