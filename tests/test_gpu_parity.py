@@ -719,3 +719,23 @@ def test_stream_forget(renderer):
             assert np.array_equal(got, g["frame_u8"])
     finally:
         renderer.stream_destroy(s_); renderer.free(d8)
+
+
+@pytest.mark.parametrize("name", ["c4_3840x2160_s64_d5", "c5_7680x4320_s256_d8", "c5_7680x4320_s256_d8_spp4"])
+def test_workload_ray_counts_are_the_device_counters(renderer, name):
+    """The ray counts bench.py quotes for configs 4 and 5 (workloads.CONFIGS) are what the counting instantiation counts
+    for those frames at full size — the same counters test_ray_counters_match_oracle pins to the oracle on small frames."""
+    from python_ray_tracer_amd import workloads, _lib as L
+    wl = workloads.build(name)
+    cam, w, h = wl["camera"], wl["w"], wl["h"]
+    renderer.set_scene(wl["spheres"], wl["lights"], wl["planes"]); renderer.set_camera(cam.position, cam.rotation)
+    renderer.set_raygen(w, h, *cam.raygen())
+    d8 = renderer.malloc(3 * w * h)
+    try:
+        renderer.reset_stats()
+        p = renderer.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], spp=wl["spp"], seed=wl["seed"], flags=L.RT_FLAG_COUNT_RAYS)
+        renderer.render_device(p, 0, w, d8, None, w * h)
+        st = renderer.stats()
+    finally:
+        renderer.free(d8)
+    assert st["closest_queries"] == wl["rays"]["closest"] and st["shadow_traced"] + st["shadow_skipped"] == wl["rays"]["shadow"]

@@ -139,3 +139,14 @@ def test_closest_hit_tie_rule_cases(oracle):
         red_naive = sp[4, naive].astype(np.float64).reshape(side, side)      # amb = 1: the pixel's R is the sphere's R
         differs = (red_naive != g[f"rgb64_{ci}"][0]).sum()
         assert differs == int(g[f"disagreeing_{ci}"]) and differs >= 30
+
+
+def test_config4_ray_counts(oracle):
+    """workloads.CONFIGS quotes the oracle's query counts for config 4 (3840x2160, 64 spheres, depth 5): re-derived here
+    (about a minute of the 8 cores; config 5's constants are checked against the device counters in the GPU tests)."""
+    from python_ray_tracer_amd import workloads
+    wl = workloads.build("c4_3840x2160_s64_d5")
+    cam = wl["camera"]
+    c = oracle.render(wl["w"], wl["h"], cam.position, cam.rotation, wl["spheres"], wl["lights"], wl["planes"], wl["amb"], wl["lamb"],
+                      wl["refl"], wl["depth"], wl["aa"], raygen=cam.raygen(), want=())["counters"]
+    assert c["closest"] == wl["rays"]["closest"] and c["shadow"] == wl["rays"]["shadow"]
