@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point rt_render (host_path_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for every launch (e.g. 4 = RT_FLAG_NO_FEEDBACK; profiling variants)")
+    ap.add_argument("--gather-root", choices=("rotate", "fixed"), default="rotate",
+                    help="N > 1: assemble batch b on rank b %% N (every rank's links carry a share of the exchange) or always on rank 0")
     ap.add_argument("--balance-rounds", type=int, default=4, help="N > 1: rounds of measured-time slab balancing before the run (0 = equal-width slabs)")
     a = ap.parse_args()
 
@@ -163,7 +165,8 @@ def main():
         nonlocal frame
         frame = frames[count - 1]
     pipe = SequencePipeline(w, h, ws, dev, dist if use_gather else None, dst=0, streams=NS, frames_per_gather=F,
-                            want_f32=True, on_frames=on_frames, bounds=bounds if use_gather else None)
+                            want_f32=True, on_frames=on_frames, bounds=bounds if use_gather else None,
+                            rotate_root=(a.gather_root == "rotate" and world > 1))
     PS = pipe.plane_stride                              # slabs are stored padded to the widest rank's width
     assert all(pipe.stream_handle(i) for i in range(NS)), "expected non-default stream handles"
 
@@ -247,6 +250,11 @@ def main():
         periods = [(done[i] - done[i - W]) / W for i in range(W, len(done))]
     if not use_gather:
         frame = pipe.last_slab()[:, :ws]
+    elif pipe.rotate_root:                              # the last batch was assembled on its own root: rank 0 checks it
+        last_root = (pipe.batches - 1) % world
+        buf = frame.clone() if rank == last_root else torch.empty((3, w, h), dtype=torch.uint8, device=dev)
+        dist.broadcast(buf, src=last_root)
+        frame = buf
 
     t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -331,7 +339,7 @@ def main():
                        "rays_traced_per_frame": traced["total_traced"] if traced else None,
                        "primary_rays_per_frame": w * h, "outputs": "uint8 (3,w,h) frame + float32 (3,w,h) pre-clip RGB",
                        "streams": NS,
-                       "parallelism": f"column slabs x{world}, frames queued round-robin on {NS} stream(s)" + (f", one RCCL gather of the uint8 slabs of {F} frames to rank 0 per {F} steps, overlapped with the next steps' renders" if use_gather else "")},
+                       "parallelism": f"column slabs x{world}, frames queued round-robin on {NS} stream(s)" + (f", one RCCL gather of the uint8 slabs of {F} frames per {F} steps to " + ("rank (batch mod N) — every frame is assembled on one rank, the ranks take turns" if pipe.rotate_root else "rank 0") + ", overlapped with the next steps' renders" if use_gather else "")},
             "frame_ms": round(ms_per_step, 5),
             "frame_ms_median": round(statistics.median(periods), 5) if periods else None,
             "frame_ms_min": round(min(periods), 5) if periods else None,

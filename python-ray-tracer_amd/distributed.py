@@ -89,9 +89,10 @@ class FrameGatherer:
     collective costs tens of microseconds however small it is, a slab of a 1080p frame renders in less, so a
     sequence of frames is assembled F at a time (fewer, larger collectives)."""
 
-    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2, batch=1, bounds=None):
+    def __init__(self, w, h, dtype, device, dist, dst=0, slots=2, batch=1, bounds=None, any_root=False):
         import torch
         self.torch, self.dist, self.dst = torch, dist, dst
+        self.any_root = bool(any_root)     # submit(..., dst=r) may name any rank: every rank holds frame and staging buffers
         self.w, self.h, self.batch = w, h, int(batch)
         assert self.batch >= 1
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -105,27 +106,31 @@ class FrameGatherer:
         # padded to the widest slab, so that the exchange is still ONE gather; the padding columns travel unused
         self.ws_pad = max(widths)
         self.pending = [None] * slots
+        self.root = [dst] * slots          # the rank each slot's exchange in flight goes to
         self.frames = self.stage = None
-        if self.rank == dst:
+        if self.rank == dst or self.any_root:
             self.frames = [torch.empty((self.batch, 3, w, h), dtype=dtype, device=device) for _ in range(slots)]
             self.stage = [torch.empty((self.world, self.batch, 3, self.ws_pad, h), dtype=dtype, device=device) for _ in range(slots)]
 
-    def submit(self, slab, slot):
+    def submit(self, slab, slot, dst=None):
         """slab: (batch, 3, ws_pad, h) contiguous; columns [0, ws) of it are this rank's pixels (ws_pad == ws for
-        equal slabs).  Render with plane_stride = ws_pad * h to fill it in place."""
+        equal slabs).  Render with plane_stride = ws_pad * h to fill it in place.  dst (any_root only): the rank
+        that assembles THIS exchange — all ranks must pass the same one."""
         assert self.pending[slot] is None, "slot still in flight: call finish(slot) first"
         if self.batch == 1 and slab.dim() == 3:
             slab = slab.unsqueeze(0)
         assert tuple(slab.shape) == (self.batch, 3, self.ws_pad, self.h) and slab.is_contiguous()
-        root = self.rank == self.dst
-        recv = [self.stage[slot][r] for r in range(self.world)] if root else None
-        self.pending[slot] = self.dist.gather(slab, recv, dst=self.dst, async_op=True)
+        dst = self.dst if dst is None else int(dst)
+        assert dst == self.dst or self.any_root
+        self.root[slot] = dst
+        recv = [self.stage[slot][r] for r in range(self.world)] if self.rank == dst else None
+        self.pending[slot] = self.dist.gather(slab, recv, dst=dst, async_op=True)
 
     def finish(self, slot):
         work = self.pending[slot]
         self.pending[slot] = None
         work.wait()
-        if self.rank != self.dst:
+        if self.rank != self.root[slot]:
             return None
         f = self.frames[slot]
         if self.equal:
@@ -164,23 +169,29 @@ class SequencePipeline:
     submit(launch) queues one frame: launch(u8, f32, stream) must enqueue the rendering of this rank's slab into
     columns [0, ws) of the (3, ws_pad, h) tensors `u8` / `f32` (plane stride = self.plane_stride elements; ws_pad = ws
     unless the ranks' slabs are unequal) on `stream` (a raw stream handle, or None on CPU, where it runs synchronously).
-    drain() completes everything queued.  on_frames(first_index, frames, count), if given, is called on `dst` for
-    every assembled batch (`frames` is (F, 3, w, h); only the first `count` are new).  Without a process group
+    drain() completes everything queued.  on_frames(first_index, frames, count), if given, is called on `dst` (with
+    rotate_root: on the batch's own root) for every assembled batch (`frames` is (F, 3, w, h); only the first `count` are new).  Without a process group
     (dist=None) nothing is exchanged and on_frames is not called; last_slab() returns the newest slab.
 
     On a CUDA/HIP device this uses torch streams and events; on CPU (the gloo tests) everything is synchronous."""
 
     def __init__(self, w, h, ws, device, dist=None, dst=0, streams=3, frames_per_gather=8, want_f32=True, on_frames=None,
-                 bounds=None):
+                 bounds=None, rotate_root=False):
         import torch
         self.torch, self.dist, self.dst, self.on_frames = torch, dist, dst, on_frames
+        # rotate_root: batch b is assembled on rank (dst + b) % world instead of always on `dst`, and on_frames is called
+        # THERE.  With every frame converging on one rank, that rank's inbound links carry (world-1)/world of every frame;
+        # at 8 GPUs and a 15 us slab that is more than they deliver, while rotating spreads it over all ranks' links.
+        self.rotate_root = bool(rotate_root) and dist is not None
+        self.batches = 0                        # batches closed so far (all ranks count alike)
         self.gpu = torch.device(device).type == "cuda"
         self.NS = max(1, int(streams)) if self.gpu else 1
         self.F = max(1, int(frames_per_gather)) if dist is not None else 1
         self.SLOTS = 2 if dist is not None else self.NS
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.NS)] if self.gpu else [None]
         self.comm = torch.cuda.Stream(device=device) if (self.gpu and dist is not None) else None
-        self.gatherer = FrameGatherer(w, h, torch.uint8, device, dist, dst=dst, slots=self.SLOTS, batch=self.F, bounds=bounds) if dist is not None else None
+        self.gatherer = FrameGatherer(w, h, torch.uint8, device, dist, dst=dst, slots=self.SLOTS, batch=self.F, bounds=bounds,
+                                      any_root=self.rotate_root) if dist is not None else None
         if self.gatherer is not None:
             assert self.gatherer.ws == ws, "ws must be this rank's slab width under `bounds`"
         # slabs are stored padded to the widest rank's width (one gather even when the slabs are unequal): render
@@ -215,8 +226,10 @@ class SequencePipeline:
             for t in self.streams:
                 self.comm.wait_event(t.record_event())
         ctx = self.torch.cuda.stream(self.comm) if self.comm is not None else _nullcontext()
+        root = (self.dst + self.batches) % self.dist.get_world_size() if self.rotate_root else self.dst
+        self.batches += 1
         with ctx:
-            self.gatherer.submit(self.u8[slot], slot)
+            self.gatherer.submit(self.u8[slot], slot, dst=root)
 
     def submit(self, launch):
         i = self.n

@@ -215,7 +215,7 @@ def test_batched_gather(tmp_path, oracle, world, case, batch, nframes):
         assert np.array_equal(got[f"f{i}"], ref), f"frame {i}"
 
 
-def _sequence_worker(rank, world, port, batch, nframes, drains, out_path, weighted=False):
+def _sequence_worker(rank, world, port, batch, nframes, drains, out_path, weighted=False, rotate=False):
     """SequencePipeline on CPU (gloo): the slot/batch bookkeeping bench.py relies on, with drains in the middle."""
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -237,7 +237,7 @@ def _sequence_worker(rank, world, port, batch, nframes, drains, out_path, weight
         for j in range(count):
             got[first + j] = frames[j].numpy().copy()
     pipe = SequencePipeline(w, h, x1 - x0, torch.device("cpu"), dist, dst=0, streams=3, frames_per_gather=batch,
-                            want_f32=False, on_frames=on_frames, bounds=bounds)
+                            want_f32=False, on_frames=on_frames, bounds=bounds, rotate_root=rotate)
     assert pipe.plane_stride == max(b - a_ for a_, b in bounds) * h
     for i in range(nframes):
         def launch(u8, f32, stream, i=i):
@@ -249,7 +249,11 @@ def _sequence_worker(rank, world, port, batch, nframes, drains, out_path, weight
         if i + 1 in drains:
             pipe.drain()
     pipe.drain()
-    if rank == 0:
+    if rotate:                                             # batch b lands on rank b % world: every rank saves what it assembled
+        mine = [i for i in range(nframes) if (_batch_of(i, batch, drains) % world) == rank]
+        assert sorted(got) == mine, (rank, sorted(got), mine)
+        np.savez(out_path + f".rank{rank}.npz", **{f"f{i}": v for i, v in got.items()})
+    elif rank == 0:
         assert sorted(got) == list(range(nframes)), sorted(got)
         np.savez(out_path, **{f"f{i}": v for i, v in got.items()})
     else:
@@ -258,13 +262,32 @@ def _sequence_worker(rank, world, port, batch, nframes, drains, out_path, weight
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,batch,nframes,drains,weighted", [(2, 3, 10, (4,), False), (2, 1, 4, (), False), (2, 4, 9, (2, 8), False),
-                                                                 (3, 2, 7, (3,), True)])
-def test_sequence_pipeline(tmp_path, oracle, world, batch, nframes, drains, weighted):
+def _batch_of(i, batch, drains):
+    """index of the batch frame i travels in: batches hold `batch` frames and are cut short by a drain"""
+    b, fill = 0, 0
+    for j in range(i + 1):
+        if j == i:
+            return b
+        fill += 1
+        if fill == batch or (j + 1) in drains:
+            b, fill = b + 1, 0
+    return b
+
+
+@pytest.mark.parametrize("world,batch,nframes,drains,weighted,rotate", [(2, 3, 10, (4,), False, False), (2, 1, 4, (), False, False),
+                                                                        (2, 4, 9, (2, 8), False, False), (3, 2, 7, (3,), True, False),
+                                                                        (3, 2, 11, (5,), True, True), (2, 3, 8, (), False, True)])
+def test_sequence_pipeline(tmp_path, oracle, world, batch, nframes, drains, weighted, rotate):
     import torch.multiprocessing as mp
     out = str(tmp_path / "frames.npz")
-    mp.spawn(_sequence_worker, args=(world, _free_port(), batch, nframes, drains, out, weighted), nprocs=world, join=True)
-    got = np.load(out)
+    mp.spawn(_sequence_worker, args=(world, _free_port(), batch, nframes, drains, out, weighted, rotate), nprocs=world, join=True)
+    if rotate:                                             # the assembled frames are spread over the ranks
+        got = {}
+        for r_ in range(world):
+            got.update(np.load(out + f".rank{r_}.npz"))
+        assert sorted(got) == sorted(f"f{i}" for i in range(nframes))
+    else:
+        got = np.load(out)
     g = load_frame("c1_128")
     refs = [oracle.render(128, 128, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, d, False,
                           raygen=raygen_closed_form(128, 128, 45.0), want=("u8",))["u8"] for d in range(3)]
