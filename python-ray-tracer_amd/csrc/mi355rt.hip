@@ -39,7 +39,7 @@ struct rt_ctx {
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
     int chunk_mode = -1;              // -1 = by destination memory type
     int bnd_min_spheres = rt::BND_MIN_SPHERES;   // (MI355RT_BND_MINS overrides)
-    int bnd_max_spheres = 96;
+    int bnd_max_spheres = rt::BND_MAX_SPHERES;
     int lanes_primary = 0, lanes_min_spheres = 1 << 30;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -337,23 +337,22 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool aa = k.aa != 0;
     const bool count = (p->flags & RT_FLAG_COUNT_RAYS) != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    // bundle pre-cull (rt_device.h): scenes with enough spheres for a lane-per-sphere pass to pay; not with the counters
-    // (clustered scenes, S > rt::CLUSTER_MIN: measured slower with it — config 5: 22.8 against 20.6 ms; their deep, incoherent
-    // bounces dominate and gain nothing from a bundle bound)
-    const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    // Lane-owned traversal wants 128 VGPRs (4 waves/SIMD).  It pays where the scene's LDS image holds the wave-uniform
-    // register variant (5 waves/SIMD) to 4 anyway — 256 spheres: -7..-9 % at depth 5 and 8 — and loses where it costs a wave
-    // (144 spheres, depth 5: +20 %; 196 spheres: +8..+10 %).
+    // Lane-owned traversal (rt_device.h, MODE 2) wants 128 VGPRs (4 waves/SIMD).  It pays where the scene's LDS image holds
+    // the wave-uniform register variant (5 waves/SIMD) to 4 anyway — 256 spheres: -7..-9 % at depth 5 and 8 — and loses
+    // where it costs a wave (144 spheres, depth 5: +20 %; 196 spheres: +8..+10 %).
     const bool lds_bound4 = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, k.aa != 0, false, 256) * 5 > 160 * 1024;
-    const bool lanes = ctx->NC > 0 && (lds_bound4 || ctx->S >= ctx->lanes_min_spheres) && !count && !(p->flags & RT_FLAG_NO_BUNDLES);     // clustered scene: lane-owned traversal (rt_device.h)
+    const bool lanes = ctx->NC > 0 && (lds_bound4 || ctx->S >= ctx->lanes_min_spheres) && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
+    // Bundle pre-cull (MODE 1): scenes with enough spheres for a lane-per-sphere pass to pay (from 40) and few enough for
+    // four candidate words (256), flat or clustered: 49 spheres -16 %, 64 -20 %, 100 -19 %, 144 -20 %, 196 -4..-9 %.  Not
+    // together with the lane-owned traversal (MODE 3: config 5 19.6 against 18.9 ms): at 256 spheres the cluster bounds
+    // already do for the coherent bounces what four passes per query would.
+    const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !lanes && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
     const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const bool bwords = bnd;                                                        // the waves' bundle words in LDS
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bwords);
     const bool park = !count && !lanes && lds_park * (24 / wpw) <= 160 * 1024;
     const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bwords);
-    // (bundle candidates in front of the lane-owned traversal — MODE 3 in rt_device.h — measured slower on config 5:
-    // 22.0 against 19.2 ms; the passes cost more at the deep, incoherent bounces than they save at the first two)
     const void *fn = bnd ? mode_variant<1>(aa, park, lattice) : lanes ? mode_variant<2>(aa, park, lattice)
                          : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {

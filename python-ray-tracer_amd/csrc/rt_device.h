@@ -406,8 +406,20 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // ---------------------------------------------------------------------------------------------
 constexpr int BND_MIN_SPHERES = 40;      // below this the per-ray cull is cheaper than the passes (measured: 36 spheres +3 %, 49 spheres -16 %)
 constexpr int BND_LIGHTS = 8;            // lights with their own candidate masks (further lights: no pre-cull)
-constexpr int BND_WORDS = 2 + 2 * BND_LIGHTS + 2;   // closest-hit masks (2), per light (2 each), ball {C.xyz, rho} (2 words)
-struct Cand { unsigned long long w0, w1; bool on; };      // candidates of one query: spheres (flat scene) or clusters; 128 of them at most
+constexpr int CAND_WORDS = 4;            // sphere-level candidate masks: scenes of up to 256 spheres (flat or clustered)
+constexpr int BND_MAX_SPHERES = 64 * CAND_WORDS;
+constexpr int BND_Q = CAND_WORDS + 1;    // LDS words per query: the masks and a validity word
+constexpr int BND_WORDS = BND_Q * (1 + BND_LIGHTS);   // the next closest-hit query, then one query per light
+// The candidates of one query: bit k of word k / 64 = sphere SLOT k might be reached by some ray of the bundle.
+// What a query carries: which of the wave's stored queries its candidates are (q), and their state — the words
+// themselves are read from LDS chunk by chunk where the cull uses them (scalar registers are as scarce as vector ones here).
+struct CandRef {
+    int q;
+    int state;               // 0: no bundle information; 1: candidates stored; 2: stored and EMPTY (no sphere for any lane)
+    bool on;                 // == (state != 0)
+    __device__ __forceinline__ bool none() const { return state == 2; }
+};
+__device__ __forceinline__ CandRef cand_none() { return CandRef{0, 0, false}; }
 
 template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
 {
@@ -515,21 +527,6 @@ __device__ __forceinline__ unsigned long long bundle_pass(const float *otab, con
     return __builtin_amdgcn_ballot_w64(in && !cull);
 }
 
-// The candidate words of one query: spheres 0..127 of a flat scene, or the cluster bounds of a clustered one.
-template <bool ANCH>
-__device__ __forceinline__ void bundle_candidates(const Lds &lds, int S, int anchor, const Cone &k, const Ball &b,
-                                                  unsigned long long &w0, unsigned long long &w1)
-{
-    w0 = ~0ull; w1 = ~0ull;
-    if (!(k.ok && (ANCH || b.ok))) return;                                      // wave-uniform
-    const int Sp = padS(S, lds.NC), NCp = pad4(lds.NC);
-    const int items = lds.NC > 0 ? lds.NC : S;
-    const float *otab = lds.NC > 0 ? lds.csph32 : lds.sph32;
-    const float *atab = lds.NC > 0 ? lds.ctab + (size_t)anchor * NCp * CULL_STRIDE : lds.tab + (size_t)anchor * Sp * CULL_STRIDE;
-    w0 = bundle_pass<ANCH>(otab, atab, 0, items < 64 ? items : 64, k, b);
-    w1 = items > 64 ? bundle_pass<ANCH>(otab, atab, 64, items - 64 < 64 ? items - 64 : 64, k, b) : 0ull;
-}
-
 __device__ __forceinline__ void bnd_store(const Lds &lds, int word, unsigned long long v)
 {
     if ((threadIdx.x & 63u) == 0u) ((volatile unsigned long long *)lds.bnd)[word] = v;
@@ -538,6 +535,32 @@ __device__ __forceinline__ unsigned long long bnd_load(const Lds &lds, int word)
 {
     const unsigned long long v = ((volatile unsigned long long *)lds.bnd)[word];
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// The candidates of one query over the sphere slots (flat and clustered scenes alike: the float32 tables are in slot
+// order), stored as query q of the wave's bundle area: 0 = the next closest-hit query, 1 + m = the shadow query of light m.
+// Every mask goes to LDS as soon as its pass has produced it (not a scalar register more than needed stays live).
+template <bool ANCH>
+__device__ __forceinline__ void sphere_candidates(const Lds &lds, int q, int S, int anchor, const Cone &k, const Ball &b)
+{
+    if (!(k.ok && (ANCH || b.ok))) { bnd_store(lds, q * BND_Q + CAND_WORDS, 0ull); return; }     // wave-uniform
+    const int Sp = padS(S, lds.NC);
+    const float *atab = lds.tab + (size_t)anchor * Sp * CULL_STRIDE;
+    bool any = false;
+    for (int first = 0; first < S; first += 64) {
+        const unsigned long long w = bundle_pass<ANCH>(lds.sph32, atab, first, S - first < 64 ? S - first : 64, k, b);
+        bnd_store(lds, q * BND_Q + (first >> 6), w);
+        any = any || (w != 0ull);
+    }
+    bnd_store(lds, q * BND_Q + CAND_WORDS, any ? 1ull : 2ull);
+}
+__device__ __forceinline__ CandRef bnd_cand(const Lds &lds, int q)
+{
+    const int st = __builtin_amdgcn_readfirstlane((int)((volatile unsigned long long *)lds.bnd)[q * BND_Q + CAND_WORDS]);
+    return CandRef{q, st, st != 0};
+}
+__device__ __forceinline__ unsigned long long cand_word(const Lds &lds, const CandRef &c, int k0)   // candidates of slots [k0, k0 + 64)
+{
+    return bnd_load(lds, c.q * BND_Q + ((k0 >> 6) & (CAND_WORDS - 1)));
 }
 
 // Certificates of 4 consecutive table entries -> 4 mask bits (bit u set = some live lane has no certificate).
@@ -578,20 +601,24 @@ __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel
 // flow on scalar masks.
 template <bool ANCH, bool SELF>
 __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S, int anchor, int k0, int n,
-                                                          const RayF &q, int selfj, const Cand &cand)
+                                                          const RayF &q, int selfj, const CandRef &cand)
 {
     unsigned long long mask = 0ull;
     const int Sp = padS(S, lds.NC);
     lds_cf4 *sbase = pin_lds(ANCH ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0);
-    if (lds.NC > 0) {
+    if (cand.on) {                                                            // the bundle's candidates: groups of 4 slots holding one
+        const unsigned long long cw = cand_word(lds, cand, k0) & ((n == 64) ? ~0ull : ((1ull << n) - 1ull));
+        unsigned long long gm = (cw | (cw >> 1) | (cw >> 2) | (cw >> 3)) & 0x1111111111111111ull;
+        while (gm) {
+            const int j = __builtin_ctzll(gm);
+            gm &= gm - 1ull;
+            mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
+        }
+        mask &= cw;
+    } else if (lds.NC > 0) {
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
         lds_cf4 *cbase = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0);
         unsigned cm = 0;
-        if (cand.on) {                                                        // only the bundle's candidate clusters get the per-ray test
-            const unsigned bits = (unsigned)(((c0 < 64 ? cand.w0 : cand.w1) >> (c0 & 63)) & 0xFFull);
-            for (int j = 0; j < nc; j += 4) if ((bits >> j) & 0xFu) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
-            cm &= bits;
-        } else
         for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
@@ -601,15 +628,6 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
             const unsigned lohi = cull4<ANCH, SELF>(sbase + jb, q, selfj - jb, hi);
             mask |= (unsigned long long)lohi << jb;
         }
-    } else if (cand.on) {                                                     // flat scene: groups of 4 holding a candidate
-        const unsigned long long cw = (k0 == 0 ? cand.w0 : cand.w1) & ((n == 64) ? ~0ull : ((1ull << n) - 1ull));
-        unsigned long long gm = (cw | (cw >> 1) | (cw >> 2) | (cw >> 3)) & 0x1111111111111111ull;
-        while (gm) {
-            const int j = __builtin_ctzll(gm);
-            gm &= gm - 1ull;
-            mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
-        }
-        mask &= cw;
     } else {
         const int npad = pad4(n);
         for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
@@ -618,7 +636,7 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
 }
 
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const V3 &o, const V3 &R, float extent2, int self, const Cand &cd)
+                                                        const V3 &o, const V3 &R, float extent2, int self, const CandRef &cd)
 {
     RayF q = make_rayf_dir(R);
     if (anchor >= 0) {
@@ -761,16 +779,13 @@ __device__ __forceinline__ lds_cf4 *lds_f4(const float *generic)             // 
 }
 
 // One bit per cluster bound of the block [cb, cb + nc), nc <= 32: set where THIS lane's ray lacks a certificate.
-// cand: the bundle pre-cull's candidate clusters of this block (all ones without it) — a wave-uniform word; groups of 4
-// bounds without a candidate are skipped.
 template <bool ANCH>
-__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q, unsigned cand)
+__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q)
 {
     const int NCp = pad4(lds.NC);
     lds_cf4 *base = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + cb) * CULL_STRIDE : lds.csph32 + 4 * cb);
     unsigned cm = 0u;
     for (int c = 0; c < nc; c += 4) {                                         // tables are padded to a multiple of 4
-        if (((cand >> c) & 0xFu) == 0u) continue;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             asm volatile("" ::: "memory");
@@ -778,7 +793,7 @@ __device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor
             cm |= lane_open<ANCH>(e, q) ? (1u << (c + u)) : 0u;
         }
     }
-    return cm & cand & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                  // (a NaN ray opens the padding too)
+    return cm & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                         // (a NaN ray opens the padding too)
 }
 
 // the survivors among the (up to 8) spheres of the lane's own cluster, first slot kb
@@ -794,20 +809,15 @@ __device__ __forceinline__ unsigned lane_sphere_bits(const Lds &lds, int S, int 
     return nv >= CLUSTER ? sm : (sm & ((1u << nv) - 1u));
 }
 
-__device__ __forceinline__ unsigned cand_block(const Cand &cand, int cb)     // the 32 candidate bits of cluster block cb
-{
-    return cand.on ? (unsigned)((cb < 64 ? cand.w0 : cand.w1) >> (cb & 63)) : ~0u;
-}
-
 template <bool ANCH>
 __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a,
-                                              double &bestn, int &bidx, double &borig, const Cand &cand)
+                                              double &bestn, int &bidx, double &borig)
 {
     RayF q = make_rayf_dir(R);
     if constexpr (!ANCH) add_origin(q, o, p.extent2);
     for (int cb = 0; cb < lds.NC; cb += 32) {
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
-        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, cand_block(cand, cb));
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
         while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
             if (cm != 0u) {
                 const int kb = (cb + __builtin_ctz(cm)) * CLUSTER;
@@ -828,7 +838,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
 // any-hit: self = the sphere slot this lane's shadow ray starts on (-1: none); its own miss is certified by the
 // origin form's "behind" test where that holds (as in cull_mask)
 template <bool ANCH>
-__device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a, int self, const Cand &cand)
+__device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a, int self)
 {
     const bool a_sane = (a > 0.999999 && a < 1.000001);
     RayF q = make_rayf_dir(R);
@@ -843,7 +853,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
     for (int cb = 0; cb < lds.NC; cb += 32) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
-        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, cand_block(cand, cb));
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
         if (occ) cm = 0u;
         while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
             if (cm != 0u) {
@@ -867,15 +877,15 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
-template <int MODE>      // 0: wave-uniform cull; 1: + bundle pre-cull (cand); 2: lane-owned traversal of a clustered scene; 3: 2 with the pre-cull's candidate clusters
+template <int MODE>      // 0: wave-uniform cull; 1: + bundle pre-cull (cand); 2: lane-owned traversal of a clustered scene; 3: both (lane-owned where there is no bundle)
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
-                                            double &t_out, int &idx_out, int &type_out, const Cand &cand)
+                                            double &t_out, int &idx_out, int &type_out, const CandRef &cand)
 {
     constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = p.P;
     // the bundle pre-cull left no sphere any lane's ray could reach: the sphere part — including the re-normalised
     // direction only it uses — is skipped (wave-uniform)
-    const int S = (BND && (cand.w0 | cand.w1) == 0ull) ? 0 : p.S;
+    const int S = (BND && cand.none()) ? 0 : p.S;
     V3 R{0.0, 0.0, 0.0};
     double a = 1.0;
     if (!BND || S > 0) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
@@ -886,11 +896,9 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     int bidx = -1;
     // lane-owned traversal for the rays without a common anchor (bounce 1 on), where the wave's rays have parted;
     // the primary rays of a tile travel together: the wave-uniform cull below is cheaper for them
-    if (MODE >= 2 && lds.NC > 0 && (canchor < 0 || p.lanes_primary)) {
-        if (S > 0) {
-            if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig, cand);
-            else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig, cand);
-        }
+    if (MODE >= 2 && lds.NC > 0 && !cand.on && (canchor < 0 || p.lanes_primary)) {
+        if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig);
+        else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
@@ -932,11 +940,11 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 // anchor = cull-table index of the light the ray points at; self = index of the sphere the ray
 // starts on (-1: a plane), whose miss is certified by the origin-form "behind" test.
 template <int MODE>
-__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const Cand &cand, bool lanes = true)
+__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const CandRef &cand, bool lanes = true)
 {
     constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = p.P;
-    const int S = (BND && (cand.w0 | cand.w1) == 0ull) ? 0 : p.S;           // no candidate sphere for any lane (wave-uniform)
+    const int S = (BND && cand.none()) ? 0 : p.S;                           // no candidate sphere for any lane (wave-uniform)
     V3 R{0.0, 0.0, 0.0};
     double a = 1.0;
     // RT_LAZY_RENORM: the float32 cull runs on d itself (within 2^-52 of R: the same float32 values up to the
@@ -949,8 +957,8 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
 #if RT_PREFILTER
     const int canchor = (p.anchors > 0) ? anchor : -1;
 #endif
-    if (MODE >= 2 && lds.NC > 0 && lanes) {
-        if (S > 0) occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self, cand) : lanes_any<false>(lds, p, -1, o, R, a, self, cand);
+    if (MODE >= 2 && lds.NC > 0 && !cand.on && lanes) {
+        occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self) : lanes_any<false>(lds, p, -1, o, R, a, self);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
@@ -1016,7 +1024,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
-    if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type, Cand{0ull, 0ull, false});   // :53 (idle lanes masked off)
+    if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type, cand_none());   // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
     if (alive) {
@@ -1054,7 +1062,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
                 // (the shadow rays of the primary hits still travel together: wave-uniform cull unless p.lanes_primary)
-                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, Cand{0ull, 0ull, false}, anchor != 0 || p.lanes_primary);
+                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, cand_none(), anchor != 0 || p.lanes_primary);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -1085,7 +1093,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
     {
-        const Cand cc{bnd_load(lds, 0), bnd_load(lds, 1), true};
+        const CandRef cc = bnd_cand(lds, 0);
         if (alive) closest_hit<MODE>(lds, p, o, d, anchor, t, idx, type, cc);    // :53
     }
     alive = alive && (type != HIT_NONE);                                      // :56-57
@@ -1118,10 +1126,8 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     for (int m = 0; m < nl; ++m) {
         const double *g = lt + m * LT_STRIDE;
         const Cone k = cone_toward(ball, (float)g[0], (float)g[1], (float)g[2]);
-        unsigned long long w0, w1;
-        if (p.anchors > 0) bundle_candidates<true>(lds, S, 1 + m, k, ball, w0, w1);
-        else bundle_candidates<false>(lds, S, 0, Cone{-k.x, -k.y, -k.z, k.cosg, k.sing, k.ok}, ball, w0, w1);   // the rays run from the ball toward the light
-        bnd_store(lds, 2 + 2 * m, w0); bnd_store(lds, 3 + 2 * m, w1);
+        if (p.anchors > 0) sphere_candidates<true>(lds, 1 + m, S, 1 + m, k, ball);
+        else sphere_candidates<false>(lds, 1 + m, S, 0, Cone{-k.x, -k.y, -k.z, k.cosg, k.sing, k.ok}, ball);   // the rays run from the ball toward the light
     }
     if (alive) {
         volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.rec + coff;
@@ -1135,8 +1141,8 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
             const double k = p.lamb * dot3(Ld, N);                            // :99
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
-                const Cand cs = m < nl ? Cand{bnd_load(lds, 2 + 2 * m), bnd_load(lds, 3 + 2 * m), true} : Cand{~0ull, ~0ull, false};
-                const bool occluded = any_hit<MODE>(lds, p, Pt, Ld, 1 + m, self, cs);
+                const CandRef cs = m < nl ? bnd_cand(lds, 1 + m) : cand_none();
+                const bool occluded = any_hit<MODE>(lds, p, Pt, Ld, 1 + m, self, cs, anchor != 0 || p.lanes_primary);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -1149,9 +1155,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     // ---- whole wave: the reflected rays leave the ball within a cone -> candidates of the next closest-hit query
     if (!last) {
         const Cone kr = direction_cone(alive, d);
-        unsigned long long w0, w1;
-        bundle_candidates<false>(lds, S, 0, kr, ball, w0, w1);
-        bnd_store(lds, 0, w0); bnd_store(lds, 1, w1);
+        sphere_candidates<false>(lds, 0, S, 0, kr, ball);
     }
 }
 
@@ -1159,14 +1163,12 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
 __device__ __forceinline__ void primary_bundle(const Lds &lds, const KParams &p, bool alive, const V3 &d)
 {
     const Cone k = direction_cone(alive, d);
-    unsigned long long w0, w1;
-    if (p.anchors > 0) bundle_candidates<true>(lds, p.S, 0, k, Ball{0.0f, 0.0f, 0.0f, 0.0f, false}, w0, w1);
+    if (p.anchors > 0) sphere_candidates<true>(lds, 0, p.S, 0, k, Ball{0.0f, 0.0f, 0.0f, 0.0f, false});
     else {
         const float cx = (float)p.cam_o[0], cy = (float)p.cam_o[1], cz = (float)p.cam_o[2];
         const Ball b{cx, cy, cz, (__builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz)) * 0x1p-18f + 0x1p-20f, true};
-        bundle_candidates<false>(lds, p.S, 0, k, b, w0, w1);
+        sphere_candidates<false>(lds, 0, p.S, 0, k, b);
     }
-    bnd_store(lds, 0, w0); bnd_store(lds, 1, w1);
 }
 
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
