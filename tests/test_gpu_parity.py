@@ -590,7 +590,10 @@ def test_u8_hwc_image_layout(renderer):
         renderer.render(0.0, 0.6, 0.3, 1, 0, u8=True, f32=True, flags=L.RT_FLAG_U8_HWC)
 
 
-@pytest.mark.parametrize("S,Ln,P", [(1024, 3, 1), (700, 64, 64), (97, 0, 0)])
+@pytest.mark.parametrize("S,Ln,P", [(1024, 3, 1), (700, 64, 64), (97, 0, 0),
+                                    (150, 12, 2),     # bundle pre-cull without an anchored table (too many lights for its LDS budget): free-bundle passes only
+                                    (60, 10, 1),      # bundle pre-cull with more lights than it keeps masks for (8)
+                                    (256, 2, 1)])     # the largest scene with candidate masks, clustered
 def test_scene_size_limits_vs_oracle(renderer, oracle, S, Ln, P):
     """RT_MAX_SPHERES / RT_MAX_LIGHTS / RT_MAX_PLANES: LDS images beyond 64 KiB, no room for the anchored cull
     table (origin-form culling with clusters only), many lights and planes — bit-exact against the oracle."""
