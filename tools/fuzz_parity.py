@@ -18,7 +18,7 @@ r = pkg.Renderer(0)
 t0, n, bad = time.time(), 0, 0
 while time.time() - t0 < a.seconds:
     kind = int(rng.integers(0, 6))
-    S = int(rng.choice([0, 1, 3, 8, 17, 40, 97, 130, 260, 400]))
+    S = int(rng.choice([0, 1, 3, 8, 17, 40, 64, 97, 130, 200, 256, 260, 400]))
     scale = float(rng.choice([0.05, 1.0, 1.0, 1.0, 30.0]))
     sp = np.zeros((7, S), np.float32)
     sp[0:3] = rng.uniform(-5, 7, (3, S)) * scale
@@ -35,7 +35,7 @@ while time.time() - t0 < a.seconds:
         nrm = rng.normal(size=(3, P))
         if kind == 3: nrm = np.eye(3)[:, rng.integers(0, 3, P)] * rng.choice([-1.0, 1.0], P)
         pl[3:6] = nrm / np.linalg.norm(nrm, axis=0, keepdims=True); pl[6:9] = rng.integers(0, 256, (3, P))
-    Ln = int(rng.integers(0, 6))
+    Ln = int(rng.integers(0, 6)) if rng.integers(0, 8) else int(rng.integers(6, 14))     # now and then more lights than the bundle pre-cull keeps masks for
     li = (rng.uniform(-6, 8, (3, Ln)) * scale).astype(np.float32)
     if kind == 4 and S and Ln: li[:, 0] = sp[0:3, 0]          # a light at a sphere centre
     w, h = int(rng.integers(9, 70)), int(rng.integers(9, 70))
