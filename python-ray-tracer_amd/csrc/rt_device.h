@@ -47,6 +47,12 @@
 #ifndef RT_BND_MAXSIN
 #define RT_BND_MAXSIN 0.5f   // widest bundle (sine of the cone's half-angle) the pre-cull is attempted for
 #endif
+#ifndef RT_OPAQUE_ARGS
+#define RT_OPAQUE_ARGS 1
+#endif
+#ifndef RT_OPAQUE_PLANE_CODE
+#define RT_OPAQUE_PLANE_CODE 1
+#endif
 #ifndef RT_LAZY_RENORM
 #define RT_LAZY_RENORM 0
 #endif
@@ -249,8 +255,14 @@ constexpr float CULL_K_ORIGIN = 0x1p-18f;
 constexpr float CULL_K_S = 0x1p-21f;
 constexpr float CULL_K_FLOOR = 0x1p-40f;
 
+// The workgroup's dynamic LDS.  Its base is a link-time constant: reading the float64 records through this symbol (and
+// not through a pointer carried in a struct) lets every record access be a ds_read at an immediate offset of the slot
+// index — as a carried pointer the base sat in a scalar register that was spilled and re-read (v_readlane + v_mov)
+// 33 times in the bundle kernels.
+extern __shared__ double lds_raw[];
+
 struct Lds {
-    const double *rec;     // float64 records
+    __device__ __forceinline__ const double *recs() const { return lds_raw; }     // float64 records
     const float *sph32;    // Sp x {cx,cy,cz,r2}
     const float *tab;      // anchors x Sp x CULL_STRIDE
     const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
@@ -669,9 +681,30 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
 // bit for bit — the other two products are +-0 and add nothing — so 8 of the 13 operations are skipped under a
 // wave-uniform branch on the record's axis code (set by the host).
 // axis code of plane k from the kernel argument (planes 4.. use the general formula, which is exact for them too)
+// A wave-uniform kernel argument made opaque at its point of use: the value stays where it is (a scalar register), but
+// what is derived from it (a comparison, a select) is re-derived there with scalar instructions instead of being hoisted
+// out of the bounce loop into scalar registers the kernel does not have — hoisted values come back as v_readlane, a VALU
+// slot each, at every use (RT_OPAQUE_ARGS = 0 leaves it to the compiler).
+__device__ __forceinline__ int opaque(int x)
+{
+#if RT_OPAQUE_ARGS
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
+
 __device__ __forceinline__ int plane_code(const KParams &p, int k)
 {
+#if RT_OPAQUE_PLANE_CODE
+    // the decoded code and the booleans derived from it are loop-invariant, and the compiler hoists them out of the bounce
+    // loop — into scalar registers it does not have: they come back as v_readlane (a VALU slot each) at every use.
+    // Re-deriving them from the one kernel-argument word costs scalar instructions only.
+    unsigned c = p.plane_codes;
+    asm volatile("" : "+s"(c));
+    return k < 4 ? (int)(signed char)(c >> (8 * k)) : 0;
+#else
     return k < 4 ? (int)(signed char)(p.plane_codes >> (8 * k)) : 0;
+#endif
 }
 
 __device__ __forceinline__ void plane_den_num(const double *__restrict__ g, int code, const V3 &o, const V3 &d, double &den, double &num)
@@ -827,7 +860,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
                     if (sm != 0u) {
                         const int k = kb + __builtin_ctz(sm);
                         sm &= sm - 1u;
-                        sphere_closest(lds.rec + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
+                        sphere_closest(lds.recs() + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
                     }
                 }
             }
@@ -865,7 +898,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
                     if (sm != 0u) {
                         const int k = kb + __builtin_ctz(sm);
                         sm &= sm - 1u;
-                        if (sphere_any(lds.rec + k * SPH_STRIDE, o, R, a, a_sane)) { occ = true; sm = 0u; cm = 0u; }
+                        if (sphere_any(lds.recs() + k * SPH_STRIDE, o, R, a, a_sane)) { occ = true; sm = 0u; cm = 0u; }
                     }
                 }
             }
@@ -882,7 +915,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
                                             double &t_out, int &idx_out, int &type_out, const CandRef &cand)
 {
     constexpr bool BND = MODE == 1 || MODE == 3;
-    const int P = p.P;
+    const int P = opaque(p.P);
     // the bundle pre-cull left no sphere any lane's ray could reach: the sphere part — including the re-normalised
     // direction only it uses — is skipped (wave-uniform)
     const int S = (BND && cand.none()) ? 0 : p.S;
@@ -890,7 +923,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     double a = 1.0;
     if (!BND || S > 0) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
 #if RT_PREFILTER
-    const int canchor = (p.anchors > 0) ? anchor : -1;
+    const int canchor = (opaque(p.anchors) > 0) ? anchor : -1;
 #endif
     double bestn = __builtin_inf(), borig = 0.0;
     int bidx = -1;
@@ -913,7 +946,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
       while (mask) {                                          // spheres some live lane might hit, ascending
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        sphere_closest(lds.rec + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
+        sphere_closest(lds.recs() + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
       }
     }
     double best = 999.0;                                      // trace.py:17
@@ -922,7 +955,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
         const double t = bestn / a;                           // :31 / :36, once per query
         if (best > t && t > 0.0) { best = t; idx = bidx; type = HIT_SPHERE; }
     }
-    const double *pl = lds.rec + p.S * SPH_STRIDE;
+    const double *pl = lds.recs() + opaque(p.S) * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {                             // intersections.py:41-68
         const double *g = pl + k * PL_STRIDE;
         double den, num;
@@ -943,7 +976,7 @@ template <int MODE>
 __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const CandRef &cand, bool lanes = true)
 {
     constexpr bool BND = MODE == 1 || MODE == 3;
-    const int P = p.P;
+    const int P = opaque(p.P);
     const int S = (BND && cand.none()) ? 0 : p.S;                           // no candidate sphere for any lane (wave-uniform)
     V3 R{0.0, 0.0, 0.0};
     double a = 1.0;
@@ -955,7 +988,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
     bool haveR = !LAZY;
     bool occ = false;
 #if RT_PREFILTER
-    const int canchor = (p.anchors > 0) ? anchor : -1;
+    const int canchor = (opaque(p.anchors) > 0) ? anchor : -1;
 #endif
     if (MODE >= 2 && lds.NC > 0 && !cand.on && lanes) {
         occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self) : lanes_any<false>(lds, p, -1, o, R, a, self);
@@ -975,10 +1008,10 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        if (!occ) occ = sphere_any(lds.rec + k * SPH_STRIDE, o, R, a, a_sane);
+        if (!occ) occ = sphere_any(lds.recs() + k * SPH_STRIDE, o, R, a, a_sane);
       }
     }
-    const double *pl = lds.rec + p.S * SPH_STRIDE;
+    const double *pl = lds.recs() + opaque(p.S) * SPH_STRIDE;
     for (int k = 0; k < P; ++k) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         if (!occ) {
@@ -1020,7 +1053,7 @@ template <bool PARK, int WGT, bool COUNT, bool LANES>
 __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                              V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt)
 {
-    const int S = p.S, P = p.P, L = p.L;
+    const int S = p.S, P = p.P, L = opaque(p.L);
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
@@ -1031,18 +1064,18 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         V3 Pt{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                   // :60 (1.0*o is exact)
         // PARK: the object's colour is re-read from its LDS record where it is used (volatile: at the point of
         // use) instead of being held in 6 VGPRs across the shadow queries
-        const int coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : S * SPH_STRIDE + idx * PL_STRIDE + 12;
-        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.rec + coff;
+        const int coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : opaque(S) * SPH_STRIDE + idx * PL_STRIDE + 12;
+        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.recs() + coff;
         V3 colr{0.0, 0.0, 0.0};
-        if constexpr (!PARK) colr = V3{lds.rec[coff], lds.rec[coff + 1], lds.rec[coff + 2]};
+        if constexpr (!PARK) colr = V3{lds.recs()[coff], lds.recs()[coff + 1], lds.recs()[coff + 2]};
         auto col = [&](int c) -> double { if constexpr (PARK) return colp[c]; else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z); };
         V3 N, bN;
         if (type == HIT_SPHERE) {                                             // :63-66
-            const double *g = lds.rec + idx * SPH_STRIDE;
+            const double *g = lds.recs() + idx * SPH_STRIDE;
             N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});        // common.py:94-101
             bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
         } else {                                                              // :68-71
-            const double *g = lds.rec + S * SPH_STRIDE + idx * PL_STRIDE;
+            const double *g = lds.recs() + opaque(S) * SPH_STRIDE + idx * PL_STRIDE;
             N = V3{g[6], g[7], g[8]};                                         // float32-renormalised, host-side
             bN = V3{g[9], g[10], g[11]};                                      // BIAS*N as the reference rounds it
         }
@@ -1052,7 +1085,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         Park3<PARK, WGT> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
         dpark.set(d);
 
-        const double *lt = lds.rec + S * SPH_STRIDE + P * PL_STRIDE;
+        const double *lt = lds.recs() + opaque(S) * SPH_STRIDE + opaque(P) * PL_STRIDE;
         for (int m = 0; m < L; ++m) {                                         // :86-102
             const double *g = lt + m * LT_STRIDE;
             const V3 Ld = normalize3(V3{g[0] - Pt.x, g[1] - Pt.y, g[2] - Pt.z});   // common.py:84-91
@@ -1088,7 +1121,7 @@ template <bool PARK, int WGT, bool COUNT, int MODE>
 __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                                  V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt, bool last)
 {
-    const int S = p.S, P = p.P, L = p.L;
+    const int S = p.S, P = p.P, L = opaque(p.L);
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
@@ -1104,14 +1137,14 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     Park3<PARK, WGT> dpark(lds.acc, 1);
     if (alive) {
         Pt = V3{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                 // :60
-        coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : S * SPH_STRIDE + idx * PL_STRIDE + 12;
+        coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : opaque(S) * SPH_STRIDE + idx * PL_STRIDE + 12;
         V3 bN;
         if (type == HIT_SPHERE) {                                             // :63-66
-            const double *g = lds.rec + idx * SPH_STRIDE;
+            const double *g = lds.recs() + idx * SPH_STRIDE;
             N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});
             bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
         } else {                                                              // :68-71
-            const double *g = lds.rec + S * SPH_STRIDE + idx * PL_STRIDE;
+            const double *g = lds.recs() + opaque(S) * SPH_STRIDE + idx * PL_STRIDE;
             N = V3{g[6], g[7], g[8]};
             bN = V3{g[9], g[10], g[11]};
         }
@@ -1122,7 +1155,7 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
     // ---- whole wave: the hit points' ball and, per light, the spheres / clusters some shadow ray might reach
     const Ball ball = point_ball(alive, Pt);
     const int nl = L < BND_LIGHTS ? L : BND_LIGHTS;
-    const double *lt = lds.rec + S * SPH_STRIDE + P * PL_STRIDE;
+    const double *lt = lds.recs() + opaque(S) * SPH_STRIDE + opaque(P) * PL_STRIDE;
     for (int m = 0; m < nl; ++m) {
         const double *g = lt + m * LT_STRIDE;
         const Cone k = cone_toward(ball, (float)g[0], (float)g[1], (float)g[2]);
@@ -1130,9 +1163,9 @@ __device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &
         else sphere_candidates<false>(lds, 1 + m, S, 0, Cone{-k.x, -k.y, -k.z, k.cosg, k.sing, k.ok}, ball);   // the rays run from the ball toward the light
     }
     if (alive) {
-        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.rec + coff;
+        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.recs() + coff;
         V3 colr{0.0, 0.0, 0.0};
-        if constexpr (!PARK) colr = V3{lds.rec[coff], lds.rec[coff + 1], lds.rec[coff + 2]};
+        if constexpr (!PARK) colr = V3{lds.recs()[coff], lds.recs()[coff + 1], lds.recs()[coff + 2]};
         auto col = [&](int c) -> double { if constexpr (PARK) return colp[c]; else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z); };
         rgb = V3{p.amb * col(0), p.amb * col(1), p.amb * col(2)};             // :77
         for (int m = 0; m < L; ++m) {                                         // :86-102
@@ -1370,7 +1403,6 @@ template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, int
 __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
-    extern __shared__ double lds_raw[];
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     double *accum = lds_raw + nrec;
     int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK) * WG_THREADS);
@@ -1393,7 +1425,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
 #endif
     }
     __syncthreads();
-    const Lds lds{lds_raw, sph32, tab, csph32, ctab, p.NC, bnd, accum};
+    const Lds lds{sph32, tab, csph32, ctab, p.NC, bnd, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
