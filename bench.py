@@ -447,7 +447,26 @@ def host_path_ms(r, wl, np, frames=40):
                 r.render_into(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], *bufs, spp=wl["spp"], seed=wl["seed"])
             out[f"{label}_{mem}"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
             r.release_host_arrays(bufs)
-    out["note"] = "ms per frame of rt_render (kernel + D2H + sync), PCIe-inclusive; never `value`"
+    # a sequence of frames through rt_render_begin / rt_render_end: three slots, each with its own pinned arrays; the
+    # copy of one frame overlaps the rendering of the next (every frame still arrives complete in host memory)
+    for label, want32 in (("u8", False), ("u8_f32", True)):
+        slots = 3
+        bufs = [r.host_arrays(want32, pinned=True) for _ in range(slots)]
+        def seq(n):
+            for i in range(n):
+                if i >= slots:
+                    r.render_end(i % slots)
+                r.render_begin(i % slots, wl["amb"], wl["lamb"], wl["refl"], wl["depth"], wl["aa"], *bufs[i % slots], spp=wl["spp"], seed=wl["seed"])
+            for sl in range(slots):
+                r.render_end(sl)
+        seq(6)
+        t0 = time.perf_counter()
+        seq(3 * frames)
+        out[f"{label}_pinned_sequence"] = round((time.perf_counter() - t0) / (3 * frames) * 1e3, 4)
+        for b in bufs:
+            r.release_host_arrays(b)
+    out["note"] = ("ms per frame, PCIe-inclusive; never `value`.  *_pageable / *_pinned: the synchronous rt_render (kernel + D2H + sync "
+                   "per call); *_pinned_sequence: frames in flight on 3 slots (rt_render_begin / rt_render_end), every frame complete in host memory")
     return out
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 #define RT_MAX_DEPTH 16      /* entries of rt_params.refl_pow (reflection bounces) */
 #define RT_MAX_SPHERES 1024  /* scene limits: the packed scene must fit one workgroup's LDS */
 #define RT_MAX_PLANES 64
@@ -183,6 +183,18 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
  * (The reference's `result.copy_to_host()` allocates its own pageable array, main.py:51.) */
 int rt_host_alloc(rt_ctx *ctx, size_t bytes, void **hptr);
 int rt_host_free(rt_ctx *ctx, void *hptr);
+
+/* rt_render in two halves, for SEQUENCES of frames into host memory (an animation: main.py:41-51 in a loop).
+ * rt_render_begin queues the launch and the copies of one frame on the stream of `slot` (0 <= slot < RT_RENDER_SLOTS)
+ * and returns; rt_render_end(slot) returns when everything queued on that slot has arrived in the host buffers.  Frames
+ * begun on different slots render and travel side by side — the copy of one frame overlaps the rendering of the next, so
+ * with page-locked destinations (rt_host_alloc) a sequence runs at the slower of the two rates instead of their sum.
+ * A second frame begun on a slot before its rt_render_end simply queues behind the first.  The camera, ray grid and scene
+ * may be changed between two begins (each launch carries its own copy); the host buffers of a slot must stay untouched
+ * until its rt_render_end.  Arguments and results as rt_render (same bytes). */
+#define RT_RENDER_SLOTS 4
+int rt_render_begin(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32, int slot);
+int rt_render_end(rt_ctx *ctx, int slot);
 
 /* The same launch into DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = the
  * context's own stream).  Element [c, x, y] (x0 <= x < x1) is stored at

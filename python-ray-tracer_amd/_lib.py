@@ -5,12 +5,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MI355RT_SO") or os.path.join(HERE, "libmi355rt.so")   # env override: A/B profiling of other builds
 
-RT_ABI_VERSION = 4
+RT_ABI_VERSION = 5
 RT_MAX_DEPTH = 16
 RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 RT_AA_NONE, RT_AA_REFERENCE, RT_AA_STOCHASTIC = 0, 1, 2
 RT_MAX_SPP = 64
+RT_RENDER_SLOTS = 4
 RT_FLAG_TYPED_BIAS, RT_FLAG_U8_RGB, RT_FLAG_NO_FEEDBACK, RT_FLAG_U8_HWC, RT_FLAG_COUNT_RAYS, RT_FLAG_AA_PER_PIXEL, RT_FLAG_NO_BUNDLES = 1, 2, 4, 8, 16, 32, 64
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_BAD_ARG", -2: "RT_ERR_HIP", -3: "RT_ERR_NO_DEVICE", -4: "RT_ERR_STATE", -5: "RT_ERR_ALLOC"}
@@ -45,6 +46,8 @@ PROTOTYPES = {
     "rt_set_raygen": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "rt_set_pixel_loc": (C.c_int, [_vp, _dp, C.c_int, C.c_int]),
     "rt_render": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp]),
+    "rt_render_begin": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp, C.c_int]),
+    "rt_render_end": (C.c_int, [_vp, C.c_int]),
     "rt_render_device": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
     "rt_sync": (C.c_int, [_vp]),
     "rt_stream_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),

@@ -42,6 +42,10 @@ struct rt_ctx {
     int bnd_max_spheres = rt::BND_MAX_SPHERES;
     int lanes_primary = 0, lanes_min_spheres = 1 << 30;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
+    struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
+        hipStream_t stream = nullptr;
+        Buf u8, f32;
+    } slots[RT_RENDER_SLOTS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf scene, pixel_loc, u8, f32;
     int S = 0, P = 0, L = 0;
@@ -538,6 +542,10 @@ int rt_destroy(rt_ctx *ctx)
     }
     for (hipEvent_t e : ctx->spare_events) (void)hipEventDestroy(e);
     for (hipStream_t st : {ctx->stream2, ctx->copy_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto &sl : ctx->slots) {
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+        for (Buf *b : {&sl.u8, &sl.f32}) if (b->p) (void)hipFree(b->p);
+    }
     for (hipEvent_t e : ctx->chunk_ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : ctx->chunk_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -805,6 +813,43 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
                                                   n * sizeof(float), 3, hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     RT_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return RT_OK;
+}
+
+int rt_render_begin(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32, int slot)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    int rc = check_params(ctx, params, x0, x1);
+    if (rc != RT_OK) return rc;
+    if (slot < 0 || slot >= RT_RENDER_SLOTS) return fail(ctx, RT_ERR_BAD_ARG, "rt_render_begin: slot outside 0..RT_RENDER_SLOTS-1");
+    if (!out_u8 && !out_f32) return fail(ctx, RT_ERR_BAD_ARG, "both output pointers are NULL");
+    const bool hwc = (params->flags & RT_FLAG_U8_HWC) != 0;
+    if (hwc && out_f32)
+        return fail(ctx, RT_ERR_BAD_ARG, "RT_FLAG_U8_HWC: request the uint8 image and the float32 buffer in separate calls");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rt_ctx::Slot &sl = ctx->slots[slot];
+    if (!sl.stream) RT_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    // One launch and one copy per output, queued on the slot's stream: the frame before this one in the same slot is
+    // ahead of it in that stream (its staging planes are free by the time this launch writes them), the frames of the
+    // other slots render and travel beside it.  The staging planes grow on the first frame of a larger size only
+    // (hipFree waits for the device).
+    const size_t npx = (size_t)(x1 - x0) * ctx->h;
+    if (out_u8 && (rc = ensure(ctx, sl.u8, 3 * npx)) != RT_OK) return rc;
+    if (out_f32 && (rc = ensure(ctx, sl.f32, 3 * npx * sizeof(float))) != RT_OK) return rc;
+    rc = launch(ctx, params, x0, x1, out_u8 ? sl.u8.p : nullptr, out_f32 ? sl.f32.p : nullptr,
+                hwc ? (int64_t)(x1 - x0) : (int64_t)npx, sl.stream);
+    if (rc != RT_OK) return rc;
+    if (out_u8) RT_HIP(ctx, hipMemcpyAsync(out_u8, sl.u8.p, 3 * npx, hipMemcpyDeviceToHost, sl.stream));
+    if (out_f32) RT_HIP(ctx, hipMemcpyAsync(out_f32, sl.f32.p, 3 * npx * sizeof(float), hipMemcpyDeviceToHost, sl.stream));
+    return RT_OK;
+}
+
+int rt_render_end(rt_ctx *ctx, int slot)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (slot < 0 || slot >= RT_RENDER_SLOTS) return fail(ctx, RT_ERR_BAD_ARG, "rt_render_end: slot outside 0..RT_RENDER_SLOTS-1");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->slots[slot].stream) RT_HIP(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
     return RT_OK;
 }
 

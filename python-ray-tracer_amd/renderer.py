@@ -151,6 +151,22 @@ class Renderer:
                                         out8.ctypes.data if out8 is not None else None,
                                         out32.ctypes.data if out32 is not None else None))
 
+    def render_begin(self, slot, amb, lamb, refl, depth, aa, out8, out32=None, *, x0=0, x1=None, flags=0, refl_pow=None, spp=0, seed=1):
+        """render_into() without the wait: the frame is queued on `slot` (0 .. RENDER_SLOTS-1) and arrives in the arrays by
+        render_end(slot).  Frames on different slots overlap (copy of one, rendering of the next); use page-locked
+        arrays (host_array()) — a copy into pageable memory is staged by the runtime on the calling thread."""
+        x1 = (self.w or 0) if x1 is None else int(x1)
+        p = self.params(amb, lamb, refl, depth, aa, flags, refl_pow, spp, seed)
+        for a, dt in ((out8, np.uint8), (out32, np.float32)):
+            if a is not None and (a.dtype != dt or not a.flags["C_CONTIGUOUS"] or a.size != 3 * (x1 - int(x0)) * (self.h or 0)):
+                raise ValueError("output arrays must be C-contiguous uint8 / float32 with 3*(x1-x0)*h elements")
+        self._check(self._lib.rt_render_begin(self._ctx, C.byref(p), int(x0), x1,
+                                              out8.ctypes.data if out8 is not None else None,
+                                              out32.ctypes.data if out32 is not None else None, int(slot)))
+
+    def render_end(self, slot):
+        self._check(self._lib.rt_render_end(self._ctx, int(slot)))
+
     def host_array(self, shape, dtype):
         """A page-locked (pinned) numpy array owned by the library; give it back with release_host_array()."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize

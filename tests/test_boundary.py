@@ -35,7 +35,7 @@ def test_header_constants_match_python():
     from python_ray_tracer_amd import _lib
     src = open(HEADER).read()
     for name in ("RT_ABI_VERSION", "RT_MAX_DEPTH", "RT_MAX_SPHERES", "RT_MAX_PLANES", "RT_MAX_LIGHTS",
-                 "RT_AA_NONE", "RT_AA_REFERENCE", "RT_AA_STOCHASTIC", "RT_MAX_SPP", "RT_FLAG_TYPED_BIAS", "RT_FLAG_U8_RGB"):
+                 "RT_AA_NONE", "RT_AA_REFERENCE", "RT_AA_STOCHASTIC", "RT_MAX_SPP", "RT_RENDER_SLOTS", "RT_FLAG_TYPED_BIAS", "RT_FLAG_U8_RGB"):
         m = re.search(rf"#define\s+{name}\s+(-?\d+)", src)
         assert m and int(m.group(1)) == getattr(_lib, name), name
     for name, val in re.findall(r"(RT_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", src):

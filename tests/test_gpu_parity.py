@@ -203,6 +203,59 @@ def test_c2_eight_slabs_in_place_full_frame(renderer):
         renderer.free(d8); renderer.free(d32)
 
 
+def test_host_frame_sequence_over_slots(renderer, oracle):
+    """rt_render_begin / rt_render_end: frames queued on the slots without waiting arrive as the same bytes as the
+    synchronous call's — the headline frame (goldens) into page-locked arrays on every slot, two frames deep, and a
+    camera that moves between the begins (each frame its own oracle frame), float32 included."""
+    import hashlib
+    import python_ray_tracer_amd as pkg
+    from python_ray_tracer_amd import _lib
+    from python_ray_tracer_amd.scene import Camera
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    args = (float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0)
+    nslots = _lib.RT_RENDER_SLOTS
+    bufs = [renderer.host_arrays(s == 0, pinned=True) for s in range(2 * nslots)]
+    try:
+        for i, b in enumerate(bufs):                          # the second round queues behind the first on each slot
+            renderer.render_begin(i % nslots, *args, *b, refl_pow=g["refl_pow"])
+        for s in range(nslots):
+            renderer.render_end(s)
+        for b in bufs:
+            assert np.array_equal(b[0], g["frame_u8"])
+        assert hashlib.sha256(bufs[0][1].tobytes()).hexdigest() == str(g["sha256_rgb32"])
+    finally:
+        for b in bufs:
+            renderer.release_host_arrays(b)
+    with pytest.raises(pkg.RenderError):
+        renderer.render_begin(nslots, *args, np.empty((3, w, h), np.uint8))
+    with pytest.raises(pkg.RenderError):
+        renderer.render_end(-1)
+    # moving camera, pageable and page-locked destinations mixed, an unaligned column range
+    g = load_frame("default_128_d3")
+    w = h = 64
+    cams = [Camera((w, h), [-2.0 + 0.4 * i, 0.3 * i - 0.5, 2.0 + 0.1 * i], [0, -30 + 3 * i, 5 * i], fov=45.0) for i in range(6)]
+    renderer.set_scene(g["spheres"], g["lights"], g["planes"])
+    outs = [(renderer.host_array((3, 51, h), np.uint8) if i % 2 else np.empty((3, 51, h), np.uint8),
+             np.empty((3, 51, h), np.float32)) for i in range(len(cams))]
+    try:
+        for i, c in enumerate(cams):
+            renderer.set_camera(c.position, c.rotation)
+            renderer.set_raygen(w, h, *c.raygen())
+            renderer.render_begin(i % nslots, float(g["amb"]), float(g["lamb"]), float(g["refl"]), 3, 0, *outs[i], x0=5, x1=56)
+        for s in range(nslots):
+            renderer.render_end(s)
+        for i, c in enumerate(cams):
+            ref = oracle.render(w, h, c.position, c.rotation, g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
+                                float(g["refl"]), 3, False, raygen=c.raygen(), want=("u8", "f32"))
+            assert np.array_equal(outs[i][0], ref["u8"][:, 5:56]), f"frame {i}"
+            assert np.array_equal(outs[i][1], ref["f32"][:, 5:56]), f"frame {i}"
+    finally:
+        for i, o in enumerate(outs):
+            if i % 2:
+                renderer.release_host_array(o[0])
+
+
 def test_host_path_chunked_and_pinned(renderer):
     """rt_render of a large frame runs as a pipeline of column chunks (render | copy to the host): same bytes as the
     goldens, into pageable and into page-locked arrays, uint8 alone and with the float32 buffer."""

@@ -22,6 +22,23 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 r.render_into(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 0, *bufs)
             res.append(f"{'u8+f32' if want32 else 'u8'}/{'pinned' if pinned else 'pageable'} {(time.perf_counter() - t0) / n * 1e3:.3f}")
             r.release_host_arrays(bufs)
+    # frame sequences over 1..4 slots (rt_render_begin / rt_render_end), page-locked destinations
+    for want32 in (False, True):
+        for slots in (1, 2, 3, 4):
+            bufs = [r.host_arrays(want32, pinned=True) for _ in range(slots)]
+            def seq(n):
+                for i in range(n):
+                    if i >= slots:
+                        r.render_end(i % slots)
+                    r.render_begin(i % slots, wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 0, *bufs[i % slots])
+                for sl in range(slots):
+                    r.render_end(sl)
+            seq(8)
+            t0 = time.perf_counter(); n = 120
+            seq(n)
+            res.append(f"{'u8+f32' if want32 else 'u8'}/sequence{slots} {(time.perf_counter() - t0) / n * 1e3:.3f}")
+            for b in bufs:
+                r.release_host_arrays(b)
     # the bare copy of the uint8 frame
     d = r.malloc(3 * w * h)
     for pinned in (False, True):
