@@ -42,6 +42,7 @@ struct rt_ctx {
     int bnd_max_spheres = rt::BND_MAX_SPHERES;
     int lanes_primary = 0, lanes_min_spheres = 1 << 30;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
+    int order_group = 0;              // MI355RT_ORDER_GROUP: log2 of the blocks per dispatch group (0..6; 0 = every block on its own)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
         hipStream_t stream = nullptr;
         Buf u8, f32;
@@ -62,7 +63,7 @@ struct rt_ctx {
     // that into the dispatch order of the next launch.  (Running that kernel on a side stream, overlapped with
     // the next render, was measured slower: the cross-stream event waits cost more than the 8 us they hide.)
     struct Feedback {
-        Buf hist, slot, order;        // cost histogram, per-block (bucket, rank), dispatch order
+        Buf hist, slot, order, group; // cost histograms, per-group (bucket, rank), dispatch order, per-group cost accumulators
         struct Key {                  // launch geometry `order` was built for (valid = false: none)
             bool valid = false;
             int x0 = 0, x1 = 0, h = 0, aa = 0, depth = 0, spp = 0, wpw = 0;
@@ -386,6 +387,11 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // order built from the previous measured launch of the same range, depth and AA mode.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
     const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
+    // XCD-affine block groups (rt::order_kernel): MI355RT_ORDER_GROUP = log2 blocks per group.  Off by default — groups of
+    // 8-32 blocks bring the write traffic of the headline frame from 41 to 32 MB (31.1 MB of pixels), but the coarser
+    // order costs more time than the traffic was costing (profiles/r02_order_group_sweep.txt: +0.3 % pipelined, +6..11 %
+    // on a single stream and on the larger scenes); the kernel is bound by instruction issue, not by HBM.
+    const int gshift = ctx->order_group > 0 ? ctx->order_group : 0;
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
     key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (bnd ? 16 : 0) + (lanes ? 32 : 0);
@@ -445,16 +451,25 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         }
         f.readers.clear();
         if (!f.hist.p) {
-            int rc0 = ensure(ctx, f.hist, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned));
+            const size_t hbytes = (size_t)rt::ORDER_BUCKETS * sizeof(unsigned);
+            int rc0 = ensure(ctx, f.hist, hbytes);
             if (rc0 != RT_OK) return rc0;
-            RT_HIP(ctx, hipMemsetAsync(f.hist.p, 0, (size_t)rt::ORDER_BUCKETS * sizeof(unsigned), stream));
+            RT_HIP(ctx, hipMemsetAsync(f.hist.p, 0, hbytes, stream));
         }
         if (f.slot.cap < (size_t)grid * sizeof(unsigned) || f.order.cap < (size_t)grid * sizeof(unsigned)) f.key.valid = false;
         int rc = ensure(ctx, f.slot, (size_t)grid * sizeof(unsigned));
         if (rc == RT_OK) rc = ensure(ctx, f.order, (size_t)grid * sizeof(unsigned));
         if (rc != RT_OK) return rc;
+        const size_t gbytes = (((size_t)grid >> gshift) + 1) * sizeof(unsigned long long);
+        if (gshift && f.group.cap < gbytes) {                                // (the render kernel leaves every accumulator at zero again)
+            if (rc == RT_OK) rc = ensure(ctx, f.group, gbytes);
+            if (rc != RT_OK) return rc;
+            RT_HIP(ctx, hipMemsetAsync(f.group.p, 0, f.group.cap, stream));
+        }
         k.hist = (unsigned *)f.hist.p;
         k.slot = (unsigned *)f.slot.p;
+        k.gstat = (unsigned long long *)f.group.p;
+        k.order_gshift = gshift;
         k.order = (f.key == key) ? (const unsigned *)f.order.p : nullptr;
     }
     void *args[] = {(void *)&k};
@@ -464,7 +479,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     if (measure) ctx->stats.launches_measuring++;
     if (measure) {
         hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
-                           (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid);
+                           (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid, gshift);
         RT_HIP(ctx, hipEventRecord(f.done, stream));
         f.builds = (f.key == key && f.epoch == ctx->epoch) ? f.builds + 1 : 1;
         f.key = key;
@@ -508,6 +523,7 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_BND_MINS")) ctx->bnd_min_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_BND_MAXS")) ctx->bnd_max_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
+    if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -529,7 +545,7 @@ int rt_destroy(rt_ctx *ctx)
         if (b->p) (void)hipFree(b->p);
     for (auto &e : ctx->lattice) if (e.second.p) (void)hipFree(e.second.p);
     for (auto &f : ctx->fbs) {
-        for (Buf *b : {&f.hist, &f.slot, &f.order}) if (b->p) (void)hipFree(b->p);
+        for (Buf *b : {&f.hist, &f.slot, &f.order, &f.group}) if (b->p) (void)hipFree(b->p);
         for (auto &r : f.readers) (void)hipEventDestroy(r.second);
         for (hipEvent_t e : f.spare) (void)hipEventDestroy(e);
         if (f.done) (void)hipEventDestroy(f.done);

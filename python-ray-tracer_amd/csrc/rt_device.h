@@ -83,7 +83,9 @@ struct KParams {
     float *out_f32;            // or nullptr
     unsigned *tile_cycles;     // or nullptr: per-tile wave cycles of this launch (rt_set_tile_stats)
     unsigned *hist;            // or nullptr: scheduler feedback, 1024 cost buckets (zero on entry)
-    unsigned *slot;            // per tile block: (bucket << 20) | arrival rank within the bucket
+    unsigned *slot;            // per block group: (bucket << 20) | arrival rank within the bucket
+    int order_gshift;          // log2 of the blocks per group of the dispatch order (order_kernel); 0 = every block on its own
+    unsigned long long *gstat; // per block group: (sum of block costs << 8) | blocks finished (zero on entry and on exit)
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from the previous launch's costs
     const float *ftab;         // the float32 cull tables of this scene / camera / depth, built once by tables_kernel
     unsigned long long *ray_counts;   // counting instantiation only (RT_FLAG_COUNT_RAYS): {closest, shadow issued, shadow skipped, hits}
@@ -383,6 +385,8 @@ __device__ __forceinline__ int order_bucket(unsigned c)
     const int msb = 31 - __builtin_clz(c);
     return ((msb - 4) << 5) | (int)((c >> (msb - 5)) & 31u);
 }
+// dispatch-order feedback (order_kernel)
+constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 1024, ORDER_XCDS = 8;
 // sphere slots in the float32 tables: whole clusters when the scene is clustered, else a multiple of 4
 __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTER : pad4(S); }
 
@@ -1511,13 +1515,33 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
         const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
         if (p.tile_cycles) p.tile_cycles[block * WAVES_PER_WG + (threadIdx.x >> 6)] = cyc;
         if (p.hist) {
-            // the workgroup's cost = sum over its waves; the wave that finishes last files the block under its
-            // cost bucket and records its arrival rank there (one device atomic per workgroup)
+            // the workgroup's cost = sum over its waves; the wave that finishes last adds it to the block GROUP's cost
+            // (order_kernel: a run of consecutive tiles that is dispatched together), and the block that completes the
+            // group files it under the bucket of its mean block cost, taking as many ranks as it has blocks
             const int expected = (p.ntiles - block * WAVES_PER_WG < WAVES_PER_WG) ? p.ntiles - block * WAVES_PER_WG : WAVES_PER_WG;
             atomicAdd(&wgstat[0], cyc >> 2);
             if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) {
-                const int bkt = order_bucket(atomicAdd(&wgstat[0], 0u));
-                p.slot[block] = ((unsigned)bkt << 20) | atomicAdd(&p.hist[bkt], 1u);
+                const unsigned mine = atomicAdd(&wgstat[0], 0u);
+                if (p.order_gshift == 0) {                                     // every block on its own
+                    const int bkt = order_bucket(mine);
+                    p.slot[block] = ((unsigned)bkt << 20) | atomicAdd(&p.hist[bkt], 1u);
+                } else {
+                    const int GB = 1 << p.order_gshift;                        // blocks per group
+                    const int nblocks = (p.ntiles + WAVES_PER_WG - 1) / WAVES_PER_WG;
+                    const int g = block >> p.order_gshift;
+                    const int in_group = (nblocks - g * GB < GB) ? nblocks - g * GB : GB;
+                    // one 64-bit atomic carries the group's cost sum and its count of finished blocks; the block that
+                    // completes the group files it under its mean block cost
+                    const unsigned long long old = atomicAdd(&p.gstat[g], ((unsigned long long)mine << 8) | 1ull);
+                    if ((int)(old & 255ull) == in_group - 1) {
+                        if (in_group == GB) {                                  // (the one short group at the end goes last anyway)
+                            const unsigned long long mean = ((old >> 8) + mine) >> p.order_gshift;
+                            const int bkt = order_bucket(mean > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)mean);
+                            p.slot[g] = ((unsigned)bkt << 20) | atomicAdd(&p.hist[bkt], 1u);
+                        }
+                        p.gstat[g] = 0ull;
+                    }
+                }
             }
         }
     }
@@ -1547,17 +1571,26 @@ __global__ __launch_bounds__(256) void aa_resolve_kernel(const KParams p)
     store_pixel(p, idx, R, G, B);
 }
 
-// Builds the next launch's dispatch order from what this launch recorded: tile blocks (4 tiles = one workgroup)
-// sorted by decreasing cost — a counting sort on a 1024-bucket logarithmic key (5 mantissa bits per octave)
-// whose histogram and within-bucket ranks the render kernel has already produced.  What is left is a prefix sum
-// over the buckets and one scatter; the output is a permutation of [0, nblocks) by construction (distinct
-// (bucket, rank) pairs map to distinct positions).  Also re-zeroes the histogram for the next launch.
-constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 1024;
+// Builds the next launch's dispatch order from what this launch recorded: longest-first, and XCD-affine.
+//
+// The dispatcher hands workgroup i to XCD i mod 8, and every XCD has its own L2.  A workgroup writes 16-pixel runs of
+// the output planes (16 B of a uint8 plane, 64 B of a float32 plane); the rest of each 128-byte line belongs to its
+// neighbours in y.  When those run on other XCDs, or on the same one much later, every fragment of the line is written
+// back on its own (WRITE_SIZE 41 MB per 1080p frame for 31 MB of pixels); written by one XCD within a short time, the
+// line is completed in that L2 and leaves it once.  So the unit of the order is a GROUP of blocks — a run of
+// ORDER_GROUP_TILES consecutive tiles (y runs fastest) — that goes to one XCD as a whole.  The groups are sorted by
+// decreasing mean block cost (a counting sort on a 1024-bucket logarithmic key, 5 mantissa bits per octave, whose
+// histogram and within-bucket ranks the render kernel has already produced: what is left is a prefix sum over the
+// buckets and one scatter) and dealt to the XCDs in turn: the group of sorted rank r belongs to XCD r mod 8, so every
+// XCD works down every eighth group of the list, and its block i sits at position 8 ((r / 8) gb + i) + r mod 8.
+// The last (fewer than 8) groups of the list share the positions behind those rows evenly, and the short group at the
+// end of the frame, if there is one, comes last.  The output is a permutation of [0, nblocks) by construction.
+// Also re-zeroes the histogram for the next launch.
 __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(unsigned *__restrict__ hist, const unsigned *__restrict__ slot,
-                                                               unsigned *__restrict__ order, int nblocks)
+                                                               unsigned *__restrict__ order, int nblocks, int gshift)
 {
     __shared__ unsigned start[ORDER_BUCKETS];
-    __shared__ unsigned scan[ORDER_BUCKETS];
+    __shared__ unsigned scan[ORDER_THREADS / 64];
     const int i = threadIdx.x;                          // ORDER_THREADS == ORDER_BUCKETS; thread i owns bucket 1023-i
     const unsigned v = hist[ORDER_BUCKETS - 1 - i];
     hist[ORDER_BUCKETS - 1 - i] = 0u;
@@ -1573,11 +1606,22 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(unsigned *__restri
     __syncthreads();
     unsigned base = 0;
     for (int w = 0; w < wv; ++w) base += scan[w];
-    start[ORDER_BUCKETS - 1 - i] = base + incl - v;     // exclusive offset of bucket 1023-i
+    start[ORDER_BUCKETS - 1 - i] = base + incl - v;     // exclusive offset (in groups) of bucket 1023-i
     __syncthreads();
+    const int gb = 1 << gshift;                         // blocks per group
+    const int full = nblocks / gb;                      // groups of gb blocks (sorted); a shorter one may follow
+    const int rows = full / ORDER_XCDS, rest = full - rows * ORDER_XCDS;
     for (int b = i; b < nblocks; b += ORDER_THREADS) {
-        const unsigned s = slot[b];
-        order[start[s >> 20] + (s & 0xFFFFFu)] = (unsigned)b;
+        const int g = b / gb, k = b - g * gb;
+        unsigned pos = (unsigned)b;                     // the short group at the end keeps its place
+        if (g < full) {
+            const unsigned s = slot[g];
+            const int r = (int)(start[s >> 20] + (s & 0xFFFFFu));
+            const int q = r / ORDER_XCDS, c = r - q * ORDER_XCDS;
+            pos = (q < rows) ? (unsigned)(ORDER_XCDS * (q * gb + k) + c)
+                             : (unsigned)(ORDER_XCDS * rows * gb + rest * k + c);
+        }
+        order[pos] = (unsigned)b;
     }
 }
 

@@ -203,6 +203,37 @@ def test_c2_eight_slabs_in_place_full_frame(renderer):
         renderer.free(d8); renderer.free(d32)
 
 
+def test_xcd_affine_dispatch_groups(monkeypatch):
+    """MI355RT_ORDER_GROUP (read at rt_create): the dispatch order is built from groups of 2^k consecutive blocks dealt
+    to the XCDs in turn (rt::order_kernel).  Any group size must yield a permutation of the blocks — every pixel of the
+    frame rendered exactly once — also when the last group is short and when fewer than 8 groups exist."""
+    import python_ray_tracer_amd as pkg
+    g = load_frame("c2_1080p")
+    small = load_frame("odd_37x29")
+    for k in ("1", "4", "6"):
+        monkeypatch.setenv("MI355RT_ORDER_GROUP", k)
+        r = pkg.Renderer(0)
+        try:
+            w, h, _ = _setup(r, g)
+            d8 = r.malloc(3 * w * h)
+            p = r.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+            for rep in range(4):                               # plain, measured, measured, settled order
+                r.render_device(p, 0, w, d8, None, w * h)
+                r.sync()
+                got = np.empty((3, w, h), np.uint8); r.d2h(got, d8)
+                assert np.array_equal(got, g["frame_u8"]), (k, rep)
+            r.free(d8)
+            assert r.stats()["launches_settled"] >= 1
+            ws, hs, _ = _setup(r, small)
+            for rep in range(4):
+                u8, _ = r.render(float(small["amb"]), float(small["lamb"]), float(small["refl"]), int(small["depth"]), int(small["aa"]),
+                                 refl_pow=small["refl_pow"])
+                co = small["coords"]
+                assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, small["u8"]), (k, rep)
+        finally:
+            r.close()
+
+
 def test_host_frame_sequence_over_slots(renderer, oracle):
     """rt_render_begin / rt_render_end: frames queued on the slots without waiting arrive as the same bytes as the
     synchronous call's — the headline frame (goldens) into page-locked arrays on every slot, two frames deep, and a
