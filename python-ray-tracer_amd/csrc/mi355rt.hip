@@ -596,10 +596,12 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
             for (int k = 0; k < S; ++k)
                 for (int i = 0; i < 3; ++i) { const double v = spheres[i * S + k]; lo[i] = std::min(lo[i], v); hi[i] = std::max(hi[i], v); }
             std::vector<uint32_t> code(S);
+            // one scale for the three axes (cells are cubes): with an axis normalised to its own span, a flat layer of
+            // spheres was sorted by height first, and clusters came out as radius classes spread over the layer
+            const double span = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
             for (int k = 0; k < S; ++k) {
                 uint32_t m = 0;
                 for (int i = 0; i < 3; ++i) {
-                    const double span = hi[i] - lo[i];
                     uint32_t q = span > 0 ? (uint32_t)std::min(1023.0, std::max(0.0, (spheres[i * S + k] - lo[i]) / span * 1023.0)) : 0u;
                     for (int b = 0; b < 10; ++b) m |= ((q >> b) & 1u) << (3 * b + i);
                 }

@@ -846,6 +846,20 @@ __device__ __forceinline__ unsigned lane_sphere_bits(const Lds &lds, int S, int 
     return nv >= CLUSTER ? sm : (sm & ((1u << nv) - 1u));
 }
 
+#ifdef RT_LANE_STATS
+// measurement build only: counters behind the per-tile cycles (p.tile_cycles[ntiles + base ..]): calls, sum of the
+// per-wave maximum, sum of ceil(total / 64), sum of the totals
+__device__ __forceinline__ void lane_stats(const KParams &p, int base, unsigned v)
+{
+    if (!p.tile_cycles) return;
+    unsigned mx = v, sum = v;
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned m2 = __shfl_xor(mx, d), s2 = __shfl_xor(sum, d); mx = m2 > mx ? m2 : mx; sum += s2; }
+    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+        unsigned *c = p.tile_cycles + p.ntiles + base;
+        atomicAdd(c + 0, 1u); atomicAdd(c + 1, mx); atomicAdd(c + 2, (sum + 63u) >> 6); atomicAdd(c + 3, sum);
+    }
+}
+#endif
 template <bool ANCH>
 __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a,
                                               double &bestn, int &bidx, double &borig)
@@ -855,11 +869,20 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
     for (int cb = 0; cb < lds.NC; cb += 32) {
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
         unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+#ifdef RT_LANE_STATS
+        lane_stats(p, 0, __builtin_popcount(cm));
+#endif
         while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
+#ifdef RT_LANE_STATS
+            unsigned smc = 0;
+#endif
             if (cm != 0u) {
                 const int kb = (cb + __builtin_ctz(cm)) * CLUSTER;
                 cm &= cm - 1u;
                 unsigned sm = lane_sphere_bits<ANCH>(lds, p.S, anchor, kb, q);
+#ifdef RT_LANE_STATS
+                smc = __builtin_popcount(sm);
+#endif
                 while (__builtin_amdgcn_ballot_w64(sm != 0u) != 0ull) {
                     if (sm != 0u) {
                         const int k = kb + __builtin_ctz(sm);
@@ -868,6 +891,9 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
                     }
                 }
             }
+#ifdef RT_LANE_STATS
+            lane_stats(p, 4, smc);
+#endif
         }
     }
 }
@@ -892,12 +918,21 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
         unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
         if (occ) cm = 0u;
+#ifdef RT_LANE_STATS
+        lane_stats(p, 8, __builtin_popcount(cm));
+#endif
         while (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
+#ifdef RT_LANE_STATS
+            unsigned smc = 0;
+#endif
             if (cm != 0u) {
                 const int kb = (cb + __builtin_ctz(cm)) * CLUSTER;
                 cm &= cm - 1u;
                 unsigned sm = lane_sphere_bits<ANCH>(lds, p.S, anchor, kb, q);
                 if (self_culled && self >= kb && self < kb + CLUSTER) sm &= ~(1u << (self - kb));
+#ifdef RT_LANE_STATS
+                smc = __builtin_popcount(sm);
+#endif
                 while (__builtin_amdgcn_ballot_w64(sm != 0u) != 0ull) {
                     if (sm != 0u) {
                         const int k = kb + __builtin_ctz(sm);
@@ -906,6 +941,9 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
                     }
                 }
             }
+#ifdef RT_LANE_STATS
+            lane_stats(p, 12, smc);
+#endif
         }
     }
     return occ;
