@@ -39,8 +39,9 @@ struct rt_ctx {
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
     int chunk_mode = -1;              // -1 = by destination memory type
     int bnd_min_spheres = rt::BND_MIN_SPHERES;   // (MI355RT_BND_MINS overrides)
-    int bnd_max_spheres = rt::BND_MAX_SPHERES;
-    int lanes_primary = 0, lanes_min_spheres = 1 << 30;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
+    int cluster_min = rt::CLUSTER_MIN;            // scenes with more spheres are stored in clusters (MI355RT_CLUSTER_MINS overrides)
+    int bnd_max_spheres = 192;                   // (MI355RT_BND_MAXS overrides; at most rt::BND_MAX_SPHERES)
+    int lanes_primary = 0, lanes_min_spheres = 193;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     int order_group = 0;              // MI355RT_ORDER_GROUP: log2 of the blocks per dispatch group (0..6; 0 = every block on its own)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
@@ -342,15 +343,12 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool aa = k.aa != 0;
     const bool count = (p->flags & RT_FLAG_COUNT_RAYS) != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    // Lane-owned traversal (rt_device.h, MODE 2) wants 128 VGPRs (4 waves/SIMD).  It pays where the scene's LDS image holds
-    // the wave-uniform register variant (5 waves/SIMD) to 4 anyway — 256 spheres: -7..-9 % at depth 5 and 8 — and loses
-    // where it costs a wave (144 spheres, depth 5: +20 %; 196 spheres: +8..+10 %).
-    const bool lds_bound4 = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, k.aa != 0, false, 256) * 5 > 160 * 1024;
-    const bool lanes = ctx->NC > 0 && (lds_bound4 || ctx->S >= ctx->lanes_min_spheres) && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    // Bundle pre-cull (MODE 1): scenes with enough spheres for a lane-per-sphere pass to pay (from 40) and few enough for
-    // four candidate words (256), flat or clustered: 49 spheres -16 %, 64 -20 %, 100 -19 %, 144 -20 %, 196 -4..-9 %.  Not
-    // together with the lane-owned traversal (MODE 3: config 5 19.6 against 18.9 ms): at 256 spheres the cluster bounds
-    // already do for the coherent bounces what four passes per query would.
+    // Lane-owned traversal (rt_device.h, MODE 2; compiled for 128 VGPRs, 4 waves/SIMD) from 193 spheres on, bundle pre-cull
+    // (MODE 1) for 40..192 spheres (three candidate words), flat or clustered.  Measured against the plain wave-uniform
+    // cull (RT_FLAG_NO_BUNDLES; profiles/r02_variant_thresholds.txt): bundles 49 spheres -17 %, 64 -23 %, 100 -10 %,
+    // 144 -5 %, 169 -9 %, but 196 +12..+17 %; lanes 196 spheres 0 % (depth 3) .. -3 % (depth 8), 256 spheres -18 %
+    // (depth 5) and -19 % (depth 8), but 100 +17 %, 144 +13 %, 169 +5 %.  Both together (MODE 3) lose to either.
+    const bool lanes = ctx->NC > 0 && ctx->S >= ctx->lanes_min_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
     const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !lanes && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
     const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
@@ -521,7 +519,8 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_LANES_PRIMARY")) ctx->lanes_primary = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_LANES_MINS")) ctx->lanes_min_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_BND_MINS")) ctx->bnd_min_spheres = std::atoi(e);
-    if (const char *e = std::getenv("MI355RT_BND_MAXS")) ctx->bnd_max_spheres = std::atoi(e);
+    if (const char *e = std::getenv("MI355RT_CLUSTER_MINS")) ctx->cluster_min = std::max(8, std::atoi(e));
+    if (const char *e = std::getenv("MI355RT_BND_MAXS")) ctx->bnd_max_spheres = std::min(std::atoi(e), (int)rt::BND_MAX_SPHERES);
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
@@ -591,7 +590,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         std::vector<int> order(S);
         std::iota(order.begin(), order.end(), 0);
         int NC = 0;
-        if (S > rt::CLUSTER_MIN) {
+        if (S > ctx->cluster_min) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             for (int k = 0; k < S; ++k)
                 for (int i = 0; i < 3; ++i) { const double v = spheres[i * S + k]; lo[i] = std::min(lo[i], v); hi[i] = std::max(hi[i], v); }

@@ -70,7 +70,7 @@ constexpr int LT_STRIDE = 4;       // x,y,z,pad
 constexpr int CL_STRIDE = 4;       // cluster bounding sphere: cx,cy,cz,R2 (global memory only; LDS holds the float32 tables)
 constexpr int CLUSTER = 8;         // spheres per cluster
 #ifndef RT_CLUSTER_MIN
-#define RT_CLUSTER_MIN 96   // measured: flat wins at S=64 (1.62 vs 1.79 ms), clusters win at S=256 (27.9 vs 39.4 ms)
+#define RT_CLUSTER_MIN 24   // measured (clusters = cubes of one Morton scale): 25 spheres -2 %, 36 -10 %, 49 -3 %, 64 -4 % against flat
 #endif
 constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, tau (one ds_read_b128)
@@ -420,7 +420,7 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 // All of it runs in wave-uniform control flow with all 64 lanes executing (lanes without a ray contribute neutral
 // values), between the divergent parts of trace_bounce; the masks wait in the wave's LDS words until the queries read them.
 // ---------------------------------------------------------------------------------------------
-constexpr int BND_MIN_SPHERES = 40;      // below this the per-ray cull is cheaper than the passes (measured: 36 spheres +3 %, 49 spheres -16 %)
+constexpr int BND_MIN_SPHERES = 56;      // below this the per-ray cull of the clustered scene is cheaper than the passes (measured: 49 spheres +1..+5 %, 64 spheres -9 %)
 constexpr int BND_LIGHTS = 8;            // lights with their own candidate masks (further lights: no pre-cull)
 constexpr int CAND_WORDS = 4;            // sphere-level candidate masks: scenes of up to 256 spheres (flat or clustered)
 constexpr int BND_MAX_SPHERES = 64 * CAND_WORDS;

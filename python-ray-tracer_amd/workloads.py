@@ -56,6 +56,7 @@ CONFIGS.update({
     "x_3840x2160_s36_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(6, 361)), None),
     "x_7680x4320_s196_d8": (7680, 4320, 8, False, lambda: _scene(grid_spheres(14, 359)), None),
     "x_3840x2160_s256_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(16, 356)), None),
+    "x_3840x2160_s169_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(13, 363)), None),
     "x_3840x2160_s100_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(10, 357)), None),
     "x_3840x2160_s144_d5": (3840, 2160, 5, False, lambda: _scene(grid_spheres(12, 358)), None),
     "x_1920x1080_s196_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(14, 359)), None),

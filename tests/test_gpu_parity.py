@@ -361,7 +361,7 @@ def test_random_scenes_vs_oracle(renderer, oracle):
     for trial in range(8):
         S, P, Ln = int(rng.integers(0, 40)), int(rng.integers(0, 4)), int(rng.integers(0, 6))
         if trial >= 6:
-            S = (130, 301)[trial - 6]          # clustered scenes (more than 96 spheres), ragged last cluster
+            S = (130, 301)[trial - 6]          # larger clustered scenes, ragged last cluster
         sp = np.zeros((7, S), np.float32)
         sp[0:3] = rng.uniform(-4, 6, (3, S)); sp[3] = rng.uniform(0.1, 1.2, S); sp[4:7] = rng.integers(0, 256, (3, S))
         pl = np.zeros((9, P), np.float32)
