@@ -350,7 +350,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // (depth 5) and -19 % (depth 8), but 100 +17 %, 144 +13 %, 169 +5 %.  Both together (MODE 3) lose to either.
     const bool lanes = ctx->NC > 0 && ctx->S >= ctx->lanes_min_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
     const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !lanes && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    const int wpw = (image <= 4608 && !count && !bnd) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
+    const int wpw = (image <= 4608 && !count && !bnd && ctx->NC == 0) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const bool bwords = bnd;                                                        // the waves' bundle words in LDS
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bwords);

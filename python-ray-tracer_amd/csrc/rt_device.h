@@ -70,9 +70,11 @@ constexpr int LT_STRIDE = 4;       // x,y,z,pad
 constexpr int CL_STRIDE = 4;       // cluster bounding sphere: cx,cy,cz,R2 (global memory only; LDS holds the float32 tables)
 constexpr int CLUSTER = 8;         // spheres per cluster
 #ifndef RT_CLUSTER_MIN
-#define RT_CLUSTER_MIN 24   // measured (clusters = cubes of one Morton scale): 25 spheres -2 %, 36 -10 %, 49 -3 %, 64 -4 % against flat
+#define RT_CLUSTER_MIN 32   // measured (clusters = cubes of one Morton scale): 36 spheres -10 %, 49 -3 %, 64 -4 % against flat; up to 25
+                            // the two-wave kernels (flat scenes only) are as fast
 #endif
 constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
+constexpr int BOX_STRIDE = 8;      // floats per cluster box: lo.xyz, -, hi.xyz, - (two ds_read_b128)
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, tau (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
 
@@ -269,6 +271,7 @@ struct Lds {
     const float *tab;      // anchors x Sp x CULL_STRIDE
     const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
     const float *ctab;     // anchors x NCp x CULL_STRIDE: cluster bounding spheres, anchored form
+    const float *cbox;     // NCp x BOX_STRIDE: cluster bounding boxes (rounded outward), for rays without an anchor
     int NC;
     unsigned long long *bnd;   // BND kernels: this wave's bundle area (BND_WORDS words): candidate masks + the hit-point ball
     double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
@@ -579,6 +582,61 @@ __device__ __forceinline__ unsigned long long cand_word(const Lds &lds, const Ca
     return bnd_load(lds, c.q * BND_Q + ((k0 >> 6) & (CAND_WORDS - 1)));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Slab test of a ray without an anchor (o, R) against a cluster's bounding box, float32, conservative: a certificate
+// that the reference reports a miss for EVERY sphere in the box.
+//   exact geometry: if the half-line o + tR, t >= 0, stays at least d outside the box, it stays d outside every sphere
+//   in it, so the reference's D = r2 - (distance to the line)^2 < -d^2 (or both roots lie behind the origin by d): its own
+//   float64 rounding (<= 2^-40 (|o|^2 + extent^2), the `floor` of the sphere certificates) cannot turn that into a hit
+//   once d >= 2^-20 sqrt(|o|^2 + extent^2);
+//   float32 ray: o and R rounded to float32 move a point of the ray at parameter t by at most 2^-24 (|o| + t), and every t
+//   that matters is below |o| + extent;
+//   both are covered by growing the box by m = 2^-18 (extent + |o|_1) on every side — done on the ray instead: the lower
+//   faces are tested from o + m, the upper ones from o - m;
+//   float32 arithmetic: a face's parameter is t = fma(face, inv, c), inv = rcp(R_i) (1 ulp), c = -(o_i +- m) inv rounded:
+//   t carries a relative error below 2^-21 and an absolute one below 2^-23 |c|; c is moved by 2^-21 |c| in the direction
+//   that lowers the near parameter and raises the far one, and the final comparison allows 2^-18 relative.
+//   R_i = 0 is replaced by +-2^-40 (a change of direction far below the float32 rounding already covered).
+// Miss certificate: tfar < max(tnear (1 - 2^-18), 0).  NaN operands never certify (the caller opens everything).
+// 17 VALU instructions per box, as many as the bounding-SPHERE test it replaces, for a bound several times tighter around
+// flat or elongated clusters.
+// ---------------------------------------------------------------------------------------------
+struct RayBox { F3 inv, clo, chi; bool sane; };
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void raybox_axis(float o, float R, float m, float &inv, float &clo, float &chi)
+{
+    const float Rs = __builtin_fabsf(R) < 0x1p-40f ? __builtin_copysignf(0x1p-40f, R) : R;
+    inv = __builtin_amdgcn_rcpf(Rs);
+    const float a = -((o + m) * inv), b = -((o - m) * inv);     // lower faces from o + m, upper faces from o - m
+    const float da = __builtin_fabsf(a) * 0x1p-21f, db = __builtin_fabsf(b) * 0x1p-21f;
+    // inv > 0: the lower face is the near one (its parameter goes down, the upper face's up); inv < 0: the other way round
+    clo = inv > 0.0f ? a - da : a + da;
+    chi = inv > 0.0f ? b + db : b - db;
+}
+__device__ __forceinline__ RayBox make_raybox(const RayF &q, float extent2)   // q with its origin (add_origin)
+{
+    RayBox rb;
+    const float m = 0x1p-18f * (__builtin_sqrtf(extent2) + (__builtin_fabsf(q.o.x) + __builtin_fabsf(q.o.y) + __builtin_fabsf(q.o.z)));
+    raybox_axis(q.o.x, q.R.x, m, rb.inv.x, rb.clo.x, rb.chi.x);
+    raybox_axis(q.o.y, q.R.y, m, rb.inv.y, rb.clo.y, rb.chi.y);
+    raybox_axis(q.o.z, q.R.z, m, rb.inv.z, rb.clo.z, rb.chi.z);
+    const float chk = (q.o.x + q.o.y + q.o.z) + (q.R.x + q.R.y + q.R.z);
+    rb.sane = (chk == chk) && __builtin_fabsf(chk) < 0x1p100f;                // no NaN, no infinity among the six
+    return rb;
+}
+__device__ __forceinline__ bool box_open(const f4 lo, const f4 hi, const RayBox &rb)   // true = NO certificate
+{
+    const float ax = __builtin_fmaf(lo[0], rb.inv.x, rb.clo.x), bx = __builtin_fmaf(hi[0], rb.inv.x, rb.chi.x);
+    const float ay = __builtin_fmaf(lo[1], rb.inv.y, rb.clo.y), by = __builtin_fmaf(hi[1], rb.inv.y, rb.chi.y);
+    const float az = __builtin_fmaf(lo[2], rb.inv.z, rb.clo.z), bz = __builtin_fmaf(hi[2], rb.inv.z, rb.chi.z);
+    const float tn = vmax3(vmin(ax, bx), vmin(ay, by), vmin(az, bz));
+    const float tf = vmin3(vmax(ax, bx), vmax(ay, by), vmax(az, bz));
+    return !(tf < vmax(tn * (1.0f - 0x1p-18f), 0.0f));
+}
+
 // Certificates of 4 consecutive table entries -> 4 mask bits (bit u set = some live lane has no certificate).
 // The tables are padded with entries that always certify a miss (tau = +inf, r2 = -inf), so groups of 4 need no
 // bounds handling and use immediate LDS offsets.
@@ -633,6 +691,9 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
         mask &= cw;
     } else if (lds.NC > 0) {
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
+        // (the clusters' BOXES, which the lane-owned traversal tests for rays without an anchor, were tried here too: the
+        // extra live values cost the wave-uniform kernels more in spills than the tighter bound saves: 36-100 spheres
+        // +9..+20 %)
         lds_cf4 *cbase = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0);
         unsigned cm = 0;
         for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
@@ -816,21 +877,36 @@ __device__ __forceinline__ lds_cf4 *lds_f4(const float *generic)             // 
 }
 
 // One bit per cluster bound of the block [cb, cb + nc), nc <= 32: set where THIS lane's ray lacks a certificate.
+// Anchored rays: the bounding spheres' table of the anchor (a dot product and a compare each); the others: the boxes.
 template <bool ANCH>
-__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q)
+__device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor, int cb, int nc, const RayF &q, float extent2)
 {
-    const int NCp = pad4(lds.NC);
-    lds_cf4 *base = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + cb) * CULL_STRIDE : lds.csph32 + 4 * cb);
     unsigned cm = 0u;
-    for (int c = 0; c < nc; c += 4) {                                         // tables are padded to a multiple of 4
+    if constexpr (ANCH) {
+        const int NCp = pad4(lds.NC);
+        lds_cf4 *base = pin_lds(lds.ctab + ((size_t)anchor * NCp + cb) * CULL_STRIDE);
+        for (int c = 0; c < nc; c += 4) {                                     // tables are padded to a multiple of 4
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            asm volatile("" ::: "memory");
-            const f4 e = base[c + u];
-            cm |= lane_open<ANCH>(e, q) ? (1u << (c + u)) : 0u;
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("" ::: "memory");
+                const f4 e = base[c + u];
+                cm |= lane_open<true>(e, q) ? (1u << (c + u)) : 0u;
+            }
         }
+    } else {
+        const RayBox rb = make_raybox(q, extent2);
+        lds_cf4 *base = pin_lds(lds.cbox + (size_t)cb * BOX_STRIDE);
+        for (int c = 0; c < nc; c += 2) {                                     // (an even number of boxes is stored)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                asm volatile("" ::: "memory");
+                const f4 lo = base[2 * (c + u)], hi = base[2 * (c + u) + 1];
+                cm |= box_open(lo, hi, rb) ? (1u << (c + u)) : 0u;
+            }
+        }
+        if (!rb.sane) cm = ~0u;
     }
-    return cm & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                         // (a NaN ray opens the padding too)
+    return cm & (nc >= 32 ? ~0u : ((1u << nc) - 1u));                         // (padding, and what a NaN ray opened of it)
 }
 
 // the survivors among the (up to 8) spheres of the lane's own cluster, first slot kb
@@ -868,7 +944,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
     if constexpr (!ANCH) add_origin(q, o, p.extent2);
     for (int cb = 0; cb < lds.NC; cb += 32) {
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
-        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, p.extent2);
 #ifdef RT_LANE_STATS
         lane_stats(p, 0, __builtin_popcount(cm));
 #endif
@@ -916,7 +992,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
     for (int cb = 0; cb < lds.NC; cb += 32) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
-        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q);
+        unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, p.extent2);
         if (occ) cm = 0u;
 #ifdef RT_LANE_STATS
         lane_stats(p, 8, __builtin_popcount(cm));
@@ -1358,14 +1434,14 @@ __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anc
 {
     return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
            ((size_t)lds_offset_words(park, wgt) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
-           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + 16 +   // + workgroup cost/arrival words
+           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + (size_t)pad4(NC) * BOX_STRIDE * sizeof(float) + 16 +   // + cluster boxes, workgroup cost/arrival words
            (bnd ? (size_t)(wgt / 64) * BND_WORDS * sizeof(unsigned long long) : 0);          // + the waves' bundle words
 }
 
-// floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table
+// floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table | cluster boxes
 __host__ __device__ inline size_t table_floats(int S, int NC, int anchors)
 {
-    return (size_t)(1 + anchors) * (padS(S, NC) + pad4(NC)) * 4;
+    return (size_t)(1 + anchors) * (padS(S, NC) + pad4(NC)) * 4 + (size_t)pad4(NC) * BOX_STRIDE;
 }
 
 // The float32 cull tables (exact sphere table for the origin form; {A-c, tau} per anchor and sphere; the same two
@@ -1425,6 +1501,23 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
         t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
         t[3] = anchored_tau(ll, g[3], p.floor_anch);
     }
+    // bounding boxes of the clusters' spheres (radius = sqrt of the float32 r*r the reference tests against, a little
+    // more), every face rounded outward to float32
+    float *cbox = ctab + (size_t)p.anchors * NCp * CULL_STRIDE;
+    for (int c = threadIdx.x; c < NCp; c += TABLE_THREADS) {
+        double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+        for (int k = c * CLUSTER; k < (c + 1) * CLUSTER && k < p.S; ++k) {
+            const double *g = rec + k * SPH_STRIDE;
+            const double rad = __builtin_sqrt(g[3]) * (1.0 + 0x1p-20) + 1e-30;
+            for (int i = 0; i < 3; ++i) { lo[i] = __builtin_fmin(lo[i], g[i] - rad); hi[i] = __builtin_fmax(hi[i], g[i] + rad); }
+        }
+        float *b = cbox + (size_t)c * BOX_STRIDE;
+        for (int i = 0; i < 3; ++i) {                  // a float is within 2^-24 |x| of x: step 2^-22 |x| outward first
+            b[i] = (float)(lo[i] - (__builtin_fabs(lo[i]) * 0x1p-22 + 1e-30));
+            b[4 + i] = (float)(hi[i] + (__builtin_fabs(hi[i]) * 0x1p-22 + 1e-30));
+        }
+        b[3] = 0.0f; b[7] = 0.0f;
+    }
 }
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
@@ -1453,7 +1546,8 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
     float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
     float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
     float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
-    unsigned *wgstat = reinterpret_cast<unsigned *>(ctab + (size_t)p.anchors * NCp * CULL_STRIDE);   // {cycles, waves done}
+    float *cbox = ctab + (size_t)p.anchors * NCp * CULL_STRIDE;   // NCp boxes
+    unsigned *wgstat = reinterpret_cast<unsigned *>(cbox + (size_t)NCp * BOX_STRIDE);   // {cycles, waves done}
     unsigned long long *bnd = reinterpret_cast<unsigned long long *>(wgstat + 4) + (threadIdx.x >> 6) * BND_WORDS;   // BND: this wave's words
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
@@ -1467,7 +1561,10 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
 #endif
     }
     __syncthreads();
-    const Lds lds{sph32, tab, csph32, ctab, p.NC, bnd, accum};
+    // two-wave workgroups serve the small flat scenes only (the host sends every clustered scene to workgroups of 4): with
+    // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
+    // register optimum)
+    const Lds lds{sph32, tab, csph32, ctab, cbox, WPW == 2 ? 0 : p.NC, bnd, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
