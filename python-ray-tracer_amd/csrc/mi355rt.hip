@@ -12,6 +12,7 @@
 #include <numeric>
 #include <new>
 #include <string>
+#include <functional>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -591,22 +592,30 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         std::iota(order.begin(), order.end(), 0);
         int NC = 0;
         if (S > ctx->cluster_min) {
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            for (int k = 0; k < S; ++k)
-                for (int i = 0; i < 3; ++i) { const double v = spheres[i * S + k]; lo[i] = std::min(lo[i], v); hi[i] = std::max(hi[i], v); }
-            std::vector<uint32_t> code(S);
-            // one scale for the three axes (cells are cubes): with an axis normalised to its own span, a flat layer of
-            // spheres was sorted by height first, and clusters came out as radius classes spread over the layer
-            const double span = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-            for (int k = 0; k < S; ++k) {
-                uint32_t m = 0;
-                for (int i = 0; i < 3; ++i) {
-                    uint32_t q = span > 0 ? (uint32_t)std::min(1023.0, std::max(0.0, (spheres[i * S + k] - lo[i]) / span * 1023.0)) : 0u;
-                    for (int b = 0; b < 10; ++b) m |= ((q >> b) & 1u) << (3 * b + i);
-                }
-                code[k] = m;
-            }
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code[a] < code[b]; });
+            // Recursive median split of the centres along the longest axis of their bounding box, the left part always a
+            // whole number of clusters: every cluster but the last has exactly rt::CLUSTER spheres and is a compact block
+            // of neighbours.  (Until late in round 2: Morton order cut into runs of 8 — first with every axis scaled to its own
+            // span, which sorted a flat layer of spheres by radius; then with one scale; the split is tighter still.)
+            // Ties are broken by the caller's index, so the order is the same on every host.
+            std::function<void(int, int)> split = [&](int a, int b) {
+                const int n = b - a;
+                if (n <= rt::CLUSTER) return;
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (int j = a; j < b; ++j)
+                    for (int i = 0; i < 3; ++i) { const double v = spheres[i * S + order[j]]; lo[i] = std::min(lo[i], v); hi[i] = std::max(hi[i], v); }
+                int ax = 0;
+                for (int i = 1; i < 3; ++i) if (hi[i] - lo[i] > hi[ax] - lo[ax]) ax = i;
+                const int nc = (n + rt::CLUSTER - 1) / rt::CLUSTER;
+                const int mid = a + ((nc + 1) / 2) * rt::CLUSTER;
+                auto key = [&](int x) { const float v = spheres[ax * S + x]; return v == v ? v : 3.0e38f; };   // (a NaN sorts last)
+                std::sort(order.begin() + a, order.begin() + b, [&](int x, int y) {
+                    const float vx = key(x), vy = key(y);
+                    return vx < vy || (vx == vy && x < y);
+                });
+                split(a, mid);
+                split(mid, b);
+            };
+            split(0, S);
             NC = (S + rt::CLUSTER - 1) / rt::CLUSTER;
         }
         nclusters = NC;
@@ -646,14 +655,23 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         }
         for (int c = 0; c < NC; ++c, sp += rt::CL_STRIDE) {      // bounding sphere of cluster c (float64, inflated)
             const int j0 = c * rt::CLUSTER, j1 = std::min(S, j0 + rt::CLUSTER);
-            double C[3] = {0, 0, 0};
-            for (int j = j0; j < j1; ++j) for (int i = 0; i < 3; ++i) C[i] += spheres[i * S + order[j]];
-            for (int i = 0; i < 3; ++i) C[i] /= (j1 - j0);
-            double R = 0;
-            for (int j = j0; j < j1; ++j) {
-                const int k = order[j];
-                const double dx = spheres[0 * S + k] - C[0], dy = spheres[1 * S + k] - C[1], dz = spheres[2 * S + k] - C[2];
-                R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)spheres[3 * S + k]));
+            // centre: the centroid of the centres or the centre of their bounding box, whichever gives the smaller sphere
+            double Cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+            for (int j = j0; j < j1; ++j)
+                for (int i = 0; i < 3; ++i) {
+                    const double v = spheres[i * S + order[j]], rr = std::fabs((double)spheres[3 * S + order[j]]);
+                    Cc[0][i] += v; blo[i] = std::min(blo[i], v - rr); bhi[i] = std::max(bhi[i], v + rr);
+                }
+            for (int i = 0; i < 3; ++i) { Cc[0][i] /= (j1 - j0); Cc[1][i] = 0.5 * (blo[i] + bhi[i]); }
+            double C[3] = {0, 0, 0}, R = 1e300;
+            for (int t = 0; t < 2; ++t) {
+                double Rt = 0;
+                for (int j = j0; j < j1; ++j) {
+                    const int k = order[j];
+                    const double dx = spheres[0 * S + k] - Cc[t][0], dy = spheres[1 * S + k] - Cc[t][1], dz = spheres[2 * S + k] - Cc[t][2];
+                    Rt = std::max(Rt, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)spheres[3 * S + k]));
+                }
+                if (Rt < R || t == 0) { R = Rt; for (int i = 0; i < 3; ++i) C[i] = Cc[t][i]; }   // (NaN: keeps the centroid's)
             }
             R = R * (1.0 + 1e-6) + 1e-9;
             sp[0] = C[0]; sp[1] = C[1]; sp[2] = C[2]; sp[3] = R * R;
