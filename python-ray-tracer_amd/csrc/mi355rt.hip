@@ -39,7 +39,7 @@ struct rt_ctx {
     hipEvent_t chunk_ev[RT_RENDER_CHUNKS] = {};
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
     int chunk_mode = -1;              // -1 = by destination memory type
-    int bnd_min_spheres = rt::BND_MIN_SPHERES;   // (MI355RT_BND_MINS overrides)
+    int bnd_min_spheres = 1 << 30;               // bundle pre-cull: off unless MI355RT_BND_MINS names a size to start it at
     int cluster_min = rt::CLUSTER_MIN;            // scenes with more spheres are stored in clusters (MI355RT_CLUSTER_MINS overrides)
     int bnd_max_spheres = 192;                   // (MI355RT_BND_MAXS overrides; at most rt::BND_MAX_SPHERES)
     int lanes_primary = 0, lanes_min_spheres = 193;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
@@ -344,11 +344,13 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool aa = k.aa != 0;
     const bool count = (p->flags & RT_FLAG_COUNT_RAYS) != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    // Lane-owned traversal (rt_device.h, MODE 2; compiled for 128 VGPRs, 4 waves/SIMD) from 193 spheres on, bundle pre-cull
-    // (MODE 1) for 40..192 spheres (three candidate words), flat or clustered.  Measured against the plain wave-uniform
-    // cull (RT_FLAG_NO_BUNDLES; profiles/r02_variant_thresholds.txt): bundles 49 spheres -17 %, 64 -23 %, 100 -10 %,
-    // 144 -5 %, 169 -9 %, but 196 +12..+17 %; lanes 196 spheres 0 % (depth 3) .. -3 % (depth 8), 256 spheres -18 %
-    // (depth 5) and -19 % (depth 8), but 100 +17 %, 144 +13 %, 169 +5 %.  Both together (MODE 3) lose to either.
+    // Scenes with more than rt::CLUSTER_MIN spheres are clustered (rt_set_scene) and culled cluster by cluster; from 193
+    // spheres on with the lane-owned traversal (rt_device.h, MODE 2; compiled for 128 VGPRs, 4 waves/SIMD).  Measured against
+    // the plain wave-uniform cull of the same clusters (profiles/r02_variant_thresholds.txt): lanes 256 spheres -18..-20 %,
+    // 196 spheres +1 % (depth 3) .. -4.5 % (depth 8), 169 +2 %, 144 +10 %, 100 +17 %.
+    // The bundle pre-cull (MODE 1) paid on flat scenes and on the clusters round 2 started with (64 spheres -23 %); against
+    // clusters that are compact blocks of neighbours it loses at every size (36 spheres +25 %, 64 +7 %, 100 +7 %, 144 +12 %,
+    // 169 +9 %, 196 +28 %): it stays in the library as an option (MI355RT_BND_MINS / MI355RT_BND_MAXS), off by default.
     const bool lanes = ctx->NC > 0 && ctx->S >= ctx->lanes_min_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
     const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !lanes && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
     const int wpw = (image <= 4608 && !count && !bnd && ctx->NC == 0) ? 2 : 4;   // measured at 1080p, depth 3: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)

@@ -203,6 +203,40 @@ def test_c2_eight_slabs_in_place_full_frame(renderer):
         renderer.free(d8); renderer.free(d32)
 
 
+def test_bundle_precull_opt_in(monkeypatch, oracle):
+    """The bundle pre-cull (MODE 1 kernels) is off by default since the clusters became compact blocks; MI355RT_BND_MINS turns
+    it on from that many spheres.  Still the same pixels: config 4's golden lattice, and random scenes of 40..190 spheres
+    (flat below 33, clustered above) against the oracle, with and without the 9-tap mode."""
+    import python_ray_tracer_amd as pkg
+    monkeypatch.setenv("MI355RT_BND_MINS", "8")
+    r = pkg.Renderer(0)
+    try:
+        g = load_frame("c4_s64_d5_sub32")
+        _setup(r, g)
+        u8, f32 = _render(r, g)
+        co = g["coords"]
+        assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, g["u8"])
+        assert np.array_equal(f32[:, co[:, 0], co[:, 1]].T, g["rgb64"].astype(np.float32))
+        rng = np.random.default_rng(77)
+        from python_ray_tracer_amd.scene import Camera
+        for trial, S in enumerate((12, 40, 97, 150, 190)):
+            w, h = 72, 56
+            sp = np.zeros((7, S), np.float32)
+            sp[0:3] = rng.uniform(-4, 4, (3, S)); sp[2] = np.abs(sp[2]) * 0.4 + 0.1
+            sp[3] = rng.uniform(0.1, 0.5, S); sp[4:7] = rng.uniform(0, 255, (3, S))
+            li = np.array([[3.0, -2.0, 0.5], [1.0, 4.0, -3.0], [6.0, 5.0, 7.0]], np.float32)[:, :2 + trial % 2]
+            pl = np.array([[0, 0, 0, 0, 0, 1, 120, 130, 140]], np.float32).T
+            cam = Camera((w, h), [-6.0, 0.5 * trial, 2.5], [0, -20, 3 * trial], fov=50.0)
+            r.set_scene(sp, li, pl); r.set_camera(cam.position, cam.rotation); r.set_raygen(w, h, *cam.raygen())
+            depth, aa = 1 + trial, bool(trial % 2)
+            u8, f32 = r.render(0.1, 0.6, 0.4, depth, aa, u8=True, f32=True)
+            ref = oracle.render(w, h, cam.position, cam.rotation, sp, li, pl, 0.1, 0.6, 0.4, depth, aa, raygen=cam.raygen(), want=("u8", "f32"))
+            assert np.array_equal(u8, ref["u8"]), f"S={S}: {(u8 != ref['u8']).any(axis=0).sum()} px differ"
+            assert np.array_equal(f32, ref["f32"]), f"S={S}"
+    finally:
+        r.close()
+
+
 def test_xcd_affine_dispatch_groups(monkeypatch):
     """MI355RT_ORDER_GROUP (read at rt_create): the dispatch order is built from groups of 2^k consecutive blocks dealt
     to the XCDs in turn (rt::order_kernel).  Any group size must yield a permutation of the blocks — every pixel of the
