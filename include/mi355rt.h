@@ -81,8 +81,9 @@ typedef enum rt_status {
 #define RT_FLAG_AA_PER_PIXEL 32 /* RT_AA_REFERENCE: trace all nine taps of every pixel (what the reference does, kernels.py:29-65)
                                   instead of tracing each half-pixel lattice sample once and summing nine per pixel — the
                                   default on the closed-form grid, same bytes, 4 instead of 9 samples per pixel */
-#define RT_FLAG_NO_BUNDLES 64 /* scenes with 40 spheres or more: skip the wave-level bundle pre-cull / lane-owned traversal (one lane-per-sphere pass per
-                                query in front of the per-ray cull, rt_device.h).  Same pixels; for A/B timing. */
+#define RT_FLAG_NO_BUNDLES 64 /* use the plain wave-uniform cull where the library would pick the lane-owned traversal (clustered scenes
+                                with 193 spheres or more) or, if MI355RT_BND_MINS enabled it, the bundle pre-cull (rt_device.h).
+                                Same pixels; for A/B timing. */
 #define RT_FLAG_COUNT_RAYS 16 /* run the counting instantiation of the kernel (slower: registers instead of LDS-parked
                                 state): adds this launch's ray counts to the context's rt_stats.  Same pixels. */
 
