@@ -70,8 +70,8 @@ constexpr int LT_STRIDE = 4;       // x,y,z,pad
 constexpr int CL_STRIDE = 4;       // cluster bounding sphere: cx,cy,cz,R2 (global memory only; LDS holds the float32 tables)
 constexpr int CLUSTER = 8;         // spheres per cluster
 #ifndef RT_CLUSTER_MIN
-#define RT_CLUSTER_MIN 32   // measured (clusters = cubes of one Morton scale): 36 spheres -10 %, 49 -3 %, 64 -4 % against flat; up to 25
-                            // the two-wave kernels (flat scenes only) are as fast
+#define RT_CLUSTER_MIN 20   // measured (median-split clusters) against the flat scene: 16 spheres +3 % (the two-wave kernels, flat
+                            // scenes only, are faster there), 25 -7 %, 36 -20 %, 49 -17 %, 64 -13 %
 #endif
 constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
 constexpr int BOX_STRIDE = 8;      // floats per cluster box: lo.xyz, -, hi.xyz, - (two ds_read_b128)

@@ -49,6 +49,7 @@ CONFIGS = {
 }
 # not BASELINE configurations: scene sizes between them, for choosing the kernel variants' thresholds (tools/ab_bench.py)
 CONFIGS.update({
+    "x_1920x1080_s16_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(4, 364)), None),
     "x_1920x1080_s25_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(5, 360)), None),
     "x_1920x1080_s36_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(6, 361)), None),
     "x_1920x1080_s49_d3": (1920, 1080, 3, False, lambda: _scene(grid_spheres(7, 362)), None),
