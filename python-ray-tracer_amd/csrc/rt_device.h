@@ -74,6 +74,7 @@ constexpr int CLUSTER = 8;         // spheres per cluster
                             // scenes only, are faster there), 25 -7 %, 36 -20 %, 49 -17 %, 64 -13 %
 #endif
 constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many spheres stay flat
+constexpr int SUPER = 8;           // clusters per group of clusters (one more box each: the lane-owned traversal skips whole groups)
 constexpr int BOX_STRIDE = 8;      // floats per cluster box: lo.xyz, -, hi.xyz, - (two ds_read_b128)
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, tau (one ds_read_b128)
 constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
@@ -271,7 +272,8 @@ struct Lds {
     const float *tab;      // anchors x Sp x CULL_STRIDE
     const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
     const float *ctab;     // anchors x NCp x CULL_STRIDE: cluster bounding spheres, anchored form
-    const float *cbox;     // NCp x BOX_STRIDE: cluster bounding boxes (rounded outward), for rays without an anchor
+    const float *cbox;     // NCp x BOX_STRIDE: cluster bounding boxes (rounded outward), for rays without an anchor; behind them
+                           // supers(NC) boxes around groups of SUPER clusters
     int NC;
     unsigned long long *bnd;   // BND kernels: this wave's bundle area (BND_WORDS words): candidate masks + the hit-point ball
     double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
@@ -380,6 +382,7 @@ __device__ __forceinline__ unsigned push_any(unsigned acc, lanemask m)
     return acc;
 }
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+__host__ __device__ inline int supers(int NC) { return (NC + SUPER - 1) / SUPER; }   // groups of SUPER clusters
 
 // logarithmic cost key for the dispatch-order feedback: monotone in c, < 1024
 __device__ __forceinline__ int order_bucket(unsigned c)
@@ -896,12 +899,19 @@ __device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor
     } else {
         const RayBox rb = make_raybox(q, extent2);
         lds_cf4 *base = pin_lds(lds.cbox + (size_t)cb * BOX_STRIDE);
-        for (int c = 0; c < nc; c += 2) {                                     // (an even number of boxes is stored)
+        lds_cf4 *gbase = pin_lds(lds.cbox + (size_t)(pad4(lds.NC) + cb / SUPER) * BOX_STRIDE);
+        static_assert(SUPER == 8, "a group's clusters are one byte of the mask");
+        for (int c0 = 0; c0 < nc; c0 += SUPER) {                             // a group no lane's ray enters is skipped whole
+            const bool gopen = box_open(gbase[2 * (c0 / SUPER)], gbase[2 * (c0 / SUPER) + 1], rb) || !rb.sane;
+            if (__builtin_amdgcn_ballot_w64(gopen) == 0ull) continue;
+            const int c1 = c0 + SUPER < nc ? c0 + SUPER : nc;
+            for (int c = c0; c < c1; c += 2) {                                // (an even number of boxes is stored)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                asm volatile("" ::: "memory");
-                const f4 lo = base[2 * (c + u)], hi = base[2 * (c + u) + 1];
-                cm |= box_open(lo, hi, rb) ? (1u << (c + u)) : 0u;
+                for (int u = 0; u < 2; ++u) {
+                    asm volatile("" ::: "memory");
+                    const f4 lo = base[2 * (c + u)], hi = base[2 * (c + u) + 1];
+                    cm |= box_open(lo, hi, rb) ? (1u << (c + u)) : 0u;
+                }
             }
         }
         if (!rb.sane) cm = ~0u;
@@ -1434,14 +1444,14 @@ __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anc
 {
     return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
            ((size_t)lds_offset_words(park, wgt) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
-           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + (size_t)pad4(NC) * BOX_STRIDE * sizeof(float) + 16 +   // + cluster boxes, workgroup cost/arrival words
+           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + (size_t)(pad4(NC) + supers(NC)) * BOX_STRIDE * sizeof(float) + 16 +   // + cluster and group boxes, workgroup cost/arrival words
            (bnd ? (size_t)(wgt / 64) * BND_WORDS * sizeof(unsigned long long) : 0);          // + the waves' bundle words
 }
 
-// floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table | cluster boxes
+// floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table | cluster boxes | group boxes
 __host__ __device__ inline size_t table_floats(int S, int NC, int anchors)
 {
-    return (size_t)(1 + anchors) * (padS(S, NC) + pad4(NC)) * 4 + (size_t)pad4(NC) * BOX_STRIDE;
+    return (size_t)(1 + anchors) * (padS(S, NC) + pad4(NC)) * 4 + (size_t)(pad4(NC) + supers(NC)) * BOX_STRIDE;
 }
 
 // The float32 cull tables (exact sphere table for the origin form; {A-c, tau} per anchor and sphere; the same two
@@ -1518,6 +1528,17 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
         }
         b[3] = 0.0f; b[7] = 0.0f;
     }
+    __syncthreads();
+    for (int g = threadIdx.x; g < supers(p.NC); g += TABLE_THREADS) {       // the union of the group's (outward-rounded) boxes
+        float *b = cbox + (size_t)(NCp + g) * BOX_STRIDE;
+        for (int i = 0; i < 3; ++i) { b[i] = __builtin_inff(); b[4 + i] = -__builtin_inff(); }
+        for (int c = g * SUPER; c < (g + 1) * SUPER && c < p.NC; ++c)
+            for (int i = 0; i < 3; ++i) {
+                b[i] = __builtin_fminf(b[i], cbox[(size_t)c * BOX_STRIDE + i]);
+                b[4 + i] = __builtin_fmaxf(b[4 + i], cbox[(size_t)c * BOX_STRIDE + 4 + i]);
+            }
+        b[3] = 0.0f; b[7] = 0.0f;
+    }
 }
 
 // AA = false: aliasing off — instantiated separately so that the common case does not carry the tap loop's
@@ -1547,7 +1568,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
     float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
     float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
     float *cbox = ctab + (size_t)p.anchors * NCp * CULL_STRIDE;   // NCp boxes
-    unsigned *wgstat = reinterpret_cast<unsigned *>(cbox + (size_t)NCp * BOX_STRIDE);   // {cycles, waves done}
+    unsigned *wgstat = reinterpret_cast<unsigned *>(cbox + (size_t)(NCp + supers(p.NC)) * BOX_STRIDE);   // {cycles, waves done}
     unsigned long long *bnd = reinterpret_cast<unsigned long long *>(wgstat + 4) + (threadIdx.x >> 6) * BND_WORDS;   // BND: this wave's words
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
