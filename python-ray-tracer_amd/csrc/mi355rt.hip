@@ -358,7 +358,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool bwords = bnd;                                                        // the waves' bundle words in LDS
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bwords);
     const bool park = !count && !lanes && lds_park * (24 / wpw) <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bwords);
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bwords, lanes && k.anchors > 0);
     const void *fn = bnd ? mode_variant<1>(aa, park, lattice) : lanes ? mode_variant<2>(aa, park, lattice)
                          : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
@@ -622,7 +622,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         }
         nclusters = NC;
         std::vector<double> rec((size_t)S * rt::SPH_STRIDE + (size_t)P * rt::PL_STRIDE + (size_t)L * rt::LT_STRIDE +
-                                (size_t)NC * rt::CL_STRIDE + 1, 0.0);
+                                (size_t)(NC + rt::supers(NC)) * rt::CL_STRIDE + 1, 0.0);
         double *sp = rec.data();
         unsigned codes = 0;
         for (int slot = 0; slot < S; ++slot, sp += rt::SPH_STRIDE) {
@@ -655,9 +655,9 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
         for (int k = 0; k < L; ++k, sp += rt::LT_STRIDE) {
             sp[0] = lights[0 * L + k]; sp[1] = lights[1 * L + k]; sp[2] = lights[2 * L + k];
         }
-        for (int c = 0; c < NC; ++c, sp += rt::CL_STRIDE) {      // bounding sphere of cluster c (float64, inflated)
-            const int j0 = c * rt::CLUSTER, j1 = std::min(S, j0 + rt::CLUSTER);
-            // centre: the centroid of the centres or the centre of their bounding box, whichever gives the smaller sphere
+        // bounding sphere (float64, inflated) of the spheres in slots [j0, j1): around the centroid of the centres or the centre of
+        // their bounding box, whichever gives the smaller sphere
+        auto bound = [&](int j0, int j1, double *out) {
             double Cc[2][3] = {{0, 0, 0}, {0, 0, 0}}, blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
             for (int j = j0; j < j1; ++j)
                 for (int i = 0; i < 3; ++i) {
@@ -676,8 +676,12 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
                 if (Rt < R || t == 0) { R = Rt; for (int i = 0; i < 3; ++i) C[i] = Cc[t][i]; }   // (NaN: keeps the centroid's)
             }
             R = R * (1.0 + 1e-6) + 1e-9;
-            sp[0] = C[0]; sp[1] = C[1]; sp[2] = C[2]; sp[3] = R * R;
-        }
+            out[0] = C[0]; out[1] = C[1]; out[2] = C[2]; out[3] = R * R;
+        };
+        for (int c = 0; c < NC; ++c, sp += rt::CL_STRIDE)                   // clusters of rt::CLUSTER spheres
+            bound(c * rt::CLUSTER, std::min(S, (c + 1) * rt::CLUSTER), sp);
+        for (int g = 0; g < rt::supers(NC); ++g, sp += rt::CL_STRIDE)      // groups of rt::SUPER clusters
+            bound(g * rt::SUPER * rt::CLUSTER, std::min(S, (g + 1) * rt::SUPER * rt::CLUSTER), sp);
         RT_HIP(ctx, hipSetDevice(ctx->device));
         const size_t bytes = rec.size() * sizeof(double);
         int rc = ensure(ctx, ctx->scene, bytes);

@@ -272,8 +272,9 @@ struct Lds {
     const float *tab;      // anchors x Sp x CULL_STRIDE
     const float *csph32;   // NCp x {cx,cy,cz,R2}: cluster bounding spheres, origin form
     const float *ctab;     // anchors x NCp x CULL_STRIDE: cluster bounding spheres, anchored form
-    const float *cbox;     // NCp x BOX_STRIDE: cluster bounding boxes (rounded outward), for rays without an anchor; behind them
-                           // supers(NC) boxes around groups of SUPER clusters
+    const float *cbox;     // NCp x BOX_STRIDE: cluster bounding boxes (rounded outward), for rays without an anchor
+    const float *gbox;     // supers(NC) x BOX_STRIDE: boxes around groups of SUPER clusters
+    const float *gtab;     // anchors x pad4(supers(NC)) x CULL_STRIDE: the groups' bounding spheres, anchored form
     int NC;
     unsigned long long *bnd;   // BND kernels: this wave's bundle area (BND_WORDS words): candidate masks + the hit-point ball
     double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
@@ -886,20 +887,25 @@ __device__ __forceinline__ unsigned lane_cluster_bits(const Lds &lds, int anchor
 {
     unsigned cm = 0u;
     if constexpr (ANCH) {
-        const int NCp = pad4(lds.NC);
+        const int NCp = pad4(lds.NC), NGp = pad4(supers(lds.NC));
         lds_cf4 *base = pin_lds(lds.ctab + ((size_t)anchor * NCp + cb) * CULL_STRIDE);
-        for (int c = 0; c < nc; c += 4) {                                     // tables are padded to a multiple of 4
+        lds_cf4 *gbase = pin_lds(lds.gtab + ((size_t)anchor * NGp + cb / SUPER) * CULL_STRIDE);
+        for (int c0 = 0; c0 < nc; c0 += SUPER) {                             // a group no lane's ray comes near is skipped whole
+            if (__builtin_amdgcn_ballot_w64(lane_open<true>(gbase[c0 / SUPER], q)) == 0ull) continue;
+            const int c1 = c0 + SUPER < nc ? c0 + SUPER : nc;
+            for (int c = c0; c < c1; c += 4) {                                // tables are padded to a multiple of 4
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                asm volatile("" ::: "memory");
-                const f4 e = base[c + u];
-                cm |= lane_open<true>(e, q) ? (1u << (c + u)) : 0u;
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" ::: "memory");
+                    const f4 e = base[c + u];
+                    cm |= lane_open<true>(e, q) ? (1u << (c + u)) : 0u;
+                }
             }
         }
     } else {
         const RayBox rb = make_raybox(q, extent2);
         lds_cf4 *base = pin_lds(lds.cbox + (size_t)cb * BOX_STRIDE);
-        lds_cf4 *gbase = pin_lds(lds.cbox + (size_t)(pad4(lds.NC) + cb / SUPER) * BOX_STRIDE);
+        lds_cf4 *gbase = pin_lds(lds.gbox + (size_t)(cb / SUPER) * BOX_STRIDE);
         static_assert(SUPER == 8, "a group's clusters are one byte of the mask");
         for (int c0 = 0; c0 < nc; c0 += SUPER) {                             // a group no lane's ray enters is skipped whole
             const bool gopen = box_open(gbase[2 * (c0 / SUPER)], gbase[2 * (c0 / SUPER) + 1], rb) || !rb.sane;
@@ -1440,18 +1446,36 @@ __device__ __forceinline__ void store_pixel(const KParams &p, long long off, dou
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
 __host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x workgroup-size doubles
 __host__ __device__ inline int lds_offset_words(bool park, int wgt) { return park ? wgt : 0; }    // + one int32 per thread: the pixel offset
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool bnd = false)
+// The float32 tables of a scene, offsets in floats (every one a multiple of 4):
+//   sph32 | anchored table | cluster anchored table | cluster boxes | group boxes | group anchored table | cluster sph32
+// The lane-owned traversal never reads the clusters' origin-form spheres (it tests boxes), so its kernels stage — and
+// reserve LDS for — everything but that last table (`lanes`): config 5's image stays under the 4-workgroups-per-CU line.
+struct TableLayout { size_t tab, ctab, cbox, gbox, gtab, csph32, total_lanes, total; };
+__host__ __device__ inline TableLayout table_layout(int S, int NC, int anchors)
+{
+    const size_t Sp = padS(S, NC), NCp = pad4(NC), NG = supers(NC), NGp = pad4((int)NG);
+    TableLayout t;
+    size_t o = 4 * Sp;
+    t.tab = o;    o += (size_t)anchors * Sp * CULL_STRIDE;
+    t.ctab = o;   o += (size_t)anchors * NCp * CULL_STRIDE;
+    t.cbox = o;   o += NCp * BOX_STRIDE;
+    t.gbox = o;   o += NG * BOX_STRIDE;
+    t.gtab = o;   o += (size_t)anchors * NGp * CULL_STRIDE;
+    t.total_lanes = o;
+    t.csph32 = o; o += 4 * NCp;
+    t.total = o;
+    return t;
+}
+__host__ __device__ inline size_t table_floats(int S, int NC, int anchors, bool lanes = false)
+{
+    const TableLayout t = table_layout(S, NC, anchors);
+    return lanes ? t.total_lanes : t.total;
+}
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool bnd = false, bool lanes = false)
 {
     return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
-           ((size_t)lds_offset_words(park, wgt) + (size_t)(padS(S, NC) + pad4(NC)) * 4) * sizeof(float) +
-           (size_t)anchors * (padS(S, NC) + pad4(NC)) * CULL_STRIDE * sizeof(float) + (size_t)(pad4(NC) + supers(NC)) * BOX_STRIDE * sizeof(float) + 16 +   // + cluster and group boxes, workgroup cost/arrival words
+           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16 +   // + workgroup cost/arrival words
            (bnd ? (size_t)(wgt / 64) * BND_WORDS * sizeof(unsigned long long) : 0);          // + the waves' bundle words
-}
-
-// floats in the float32 tables of a scene: sph32 | anchored table | cluster sph32 | cluster anchored table | cluster boxes | group boxes
-__host__ __device__ inline size_t table_floats(int S, int NC, int anchors)
-{
-    return (size_t)(1 + anchors) * (padS(S, NC) + pad4(NC)) * 4 + (size_t)(pad4(NC) + supers(NC)) * BOX_STRIDE;
 }
 
 // The float32 cull tables (exact sphere table for the origin form; {A-c, tau} per anchor and sphere; the same two
@@ -1462,10 +1486,11 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
 {
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
+    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
     float *sph32 = out;
-    float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
-    float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
-    float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
+    float *tab = out + tl.tab;                         // anchors x Sp entries
+    float *csph32 = out + tl.csph32;
+    float *ctab = out + tl.ctab;                       // anchors x NCp entries
     const double *rec = p.scene;
     const float NINF = -__builtin_inff();
     for (int k = threadIdx.x; k < Sp; k += TABLE_THREADS) {   // exact: the scene is float32
@@ -1513,7 +1538,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
     }
     // bounding boxes of the clusters' spheres (radius = sqrt of the float32 r*r the reference tests against, a little
     // more), every face rounded outward to float32
-    float *cbox = ctab + (size_t)p.anchors * NCp * CULL_STRIDE;
+    float *cbox = out + tl.cbox;
     for (int c = threadIdx.x; c < NCp; c += TABLE_THREADS) {
         double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
         for (int k = c * CLUSTER; k < (c + 1) * CLUSTER && k < p.S; ++k) {
@@ -1530,7 +1555,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
     }
     __syncthreads();
     for (int g = threadIdx.x; g < supers(p.NC); g += TABLE_THREADS) {       // the union of the group's (outward-rounded) boxes
-        float *b = cbox + (size_t)(NCp + g) * BOX_STRIDE;
+        float *b = out + tl.gbox + (size_t)g * BOX_STRIDE;
         for (int i = 0; i < 3; ++i) { b[i] = __builtin_inff(); b[4 + i] = -__builtin_inff(); }
         for (int c = g * SUPER; c < (g + 1) * SUPER && c < p.NC; ++c)
             for (int i = 0; i < 3; ++i) {
@@ -1538,6 +1563,22 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
                 b[4 + i] = __builtin_fmaxf(b[4 + i], cbox[(size_t)c * BOX_STRIDE + 4 + i]);
             }
         b[3] = 0.0f; b[7] = 0.0f;
+    }
+    // the anchored table of the groups' bounding spheres (float64 records behind the clusters')
+    const int NG = supers(p.NC), NGp = pad4(NG);
+    const double *gr = cl + (size_t)p.NC * CL_STRIDE;
+    for (int e = threadIdx.x; e < p.anchors * NGp; e += TABLE_THREADS) {
+        const int a = e / NGp, g = e - a * NGp;
+        float *t = out + tl.gtab + (size_t)e * CULL_STRIDE;
+        if (g >= NG) { t[0] = t[1] = t[2] = 0.0f; t[3] = -NINF; continue; }
+        const double *c = gr + g * CL_STRIDE;
+        const double ax = a ? lt[(a - 1) * LT_STRIDE + 0] : p.cam_o[0];
+        const double ay = a ? lt[(a - 1) * LT_STRIDE + 1] : p.cam_o[1];
+        const double az = a ? lt[(a - 1) * LT_STRIDE + 2] : p.cam_o[2];
+        const double lx = ax - c[0], ly = ay - c[1], lz = az - c[2];
+        const double ll = lx * lx + ly * ly + lz * lz;
+        t[0] = (float)lx; t[1] = (float)ly; t[2] = (float)lz;
+        t[3] = anchored_tau(ll, c[3], p.floor_anch);
     }
 }
 
@@ -1563,19 +1604,22 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
     double *accum = lds_raw + nrec;
     int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK) * WG_THREADS);
     float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK, WG_THREADS));
-    const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
-    float *tab = sph32 + 4 * Sp;                       // anchors x Sp entries
-    float *csph32 = tab + (size_t)p.anchors * Sp * CULL_STRIDE;
-    float *ctab = csph32 + 4 * NCp;                    // anchors x NCp entries
-    float *cbox = ctab + (size_t)p.anchors * NCp * CULL_STRIDE;   // NCp boxes
-    unsigned *wgstat = reinterpret_cast<unsigned *>(cbox + (size_t)(NCp + supers(p.NC)) * BOX_STRIDE);   // {cycles, waves done}
+    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
+    // the lane-owned kernels leave the clusters' origin-form spheres in global memory: with anchored tables in place the only
+    // rays without an anchor are the reflections, and those test boxes
+    const bool LANES = MODE >= 2 && p.anchors > 0;
+    float *tab = sph32 + tl.tab;                       // anchors x Sp entries
+    float *csph32 = LANES ? nullptr : sph32 + tl.csph32;
+    float *ctab = sph32 + tl.ctab;                     // anchors x NCp entries
+    float *cbox = sph32 + tl.cbox;                     // NCp boxes
+    unsigned *wgstat = reinterpret_cast<unsigned *>(sph32 + (LANES ? tl.total_lanes : tl.total));   // {cycles, waves done}
     unsigned long long *bnd = reinterpret_cast<unsigned long long *>(wgstat + 4) + (threadIdx.x >> 6) * BND_WORDS;   // BND: this wave's words
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
         // used to be computed here, by every workgroup: 3 % of the frame's VALU instructions and a second barrier.)
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
 #if RT_PREFILTER
-        const int nf4 = (int)(table_floats(p.S, p.NC, p.anchors) / 4);
+        const int nf4 = (int)((LANES ? tl.total_lanes : tl.total) / 4);
         const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
         f4 *dst = reinterpret_cast<f4 *>(sph32);
         for (int i = threadIdx.x; i < nf4; i += WG_THREADS) dst[i] = src[i];
@@ -1585,7 +1629,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
     // two-wave workgroups serve the small flat scenes only (the host sends every clustered scene to workgroups of 4): with
     // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
     // register optimum)
-    const Lds lds{sph32, tab, csph32, ctab, cbox, WPW == 2 ? 0 : p.NC, bnd, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, bnd, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
