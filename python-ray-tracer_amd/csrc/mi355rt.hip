@@ -599,6 +599,7 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
             // of neighbours.  (Until late in round 2: Morton order cut into runs of 8 — first with every axis scaled to its own
             // span, which sorted a flat layer of spheres by radius; then with one scale; the split is tighter still.)
             // Ties are broken by the caller's index, so the order is the same on every host.
+            const bool group_aligned = S >= ctx->lanes_min_spheres;
             std::function<void(int, int)> split = [&](int a, int b) {
                 const int n = b - a;
                 if (n <= rt::CLUSTER) return;
@@ -608,7 +609,10 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
                 int ax = 0;
                 for (int i = 1; i < 3; ++i) if (hi[i] - lo[i] > hi[ax] - lo[ax]) ax = i;
                 const int nc = (n + rt::CLUSTER - 1) / rt::CLUSTER;
-                const int mid = a + ((nc + 1) / 2) * rt::CLUSTER;
+                // scenes whose kernels test GROUPS of rt::SUPER consecutive clusters first (the lane-owned traversal's): the left
+                // part is a whole number of groups as well, so that every group is a subtree of this split
+                const int left = (group_aligned && nc > rt::SUPER) ? rt::SUPER * ((nc / rt::SUPER + 1) / 2) : (nc + 1) / 2;
+                const int mid = a + left * rt::CLUSTER;
                 auto key = [&](int x) { const float v = spheres[ax * S + x]; return v == v ? v : 3.0e38f; };   // (a NaN sorts last)
                 std::sort(order.begin() + a, order.begin() + b, [&](int x, int y) {
                     const float vx = key(x), vy = key(y);
