@@ -42,7 +42,7 @@ struct rt_ctx {
     int bnd_min_spheres = 1 << 30;               // bundle pre-cull: off unless MI355RT_BND_MINS names a size to start it at
     int cluster_min = rt::CLUSTER_MIN;            // scenes with more spheres are stored in clusters (MI355RT_CLUSTER_MINS overrides)
     int bnd_max_spheres = 192;                   // (MI355RT_BND_MAXS overrides; at most rt::BND_MAX_SPHERES)
-    int lanes_primary = 0, lanes_min_spheres = 193;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
+    int lanes_primary = 0, lanes_min_spheres = 161;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (force the lane-owned traversal from that size on)         // bundle pre-cull for scenes up to this size (MI355RT_BND_MAXS overrides)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     int order_group = 0;              // MI355RT_ORDER_GROUP: log2 of the blocks per dispatch group (0..6; 0 = every block on its own)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
@@ -344,10 +344,11 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool aa = k.aa != 0;
     const bool count = (p->flags & RT_FLAG_COUNT_RAYS) != 0;
     const size_t image = rt::lds_doubles(ctx->S, ctx->P, ctx->L) * sizeof(double) + rt::table_floats(ctx->S, ctx->NC, k.anchors) * sizeof(float);
-    // Scenes with more than rt::CLUSTER_MIN spheres are clustered (rt_set_scene) and culled cluster by cluster; from 193
-    // spheres on with the lane-owned traversal (rt_device.h, MODE 2; compiled for 128 VGPRs, 4 waves/SIMD).  Measured against
-    // the plain wave-uniform cull of the same clusters (profiles/r02_variant_thresholds.txt): lanes 256 spheres -18..-20 %,
-    // 196 spheres +1 % (depth 3) .. -4.5 % (depth 8), 169 +2 %, 144 +10 %, 100 +17 %.
+    // Scenes with more than rt::CLUSTER_MIN spheres are clustered (rt_set_scene) and culled cluster by cluster; from 161
+    // spheres on with the lane-owned traversal and its groups of clusters (rt_device.h, MODE 2; compiled for 128 VGPRs,
+    // 4 waves/SIMD).  Measured against the plain wave-uniform cull of the same clusters
+    // (profiles/r02_variant_thresholds.txt): 256 spheres -25 %, 196 spheres -4 % (depth 3) .. -9 % (depth 8), 169 -8 %,
+    // but 144 +6 %, 100 +17 %.
     // The bundle pre-cull (MODE 1) paid on flat scenes and on the clusters round 2 started with (64 spheres -23 %); against
     // clusters that are compact blocks of neighbours it loses at every size (36 spheres +25 %, 64 +7 %, 100 +7 %, 144 +12 %,
     // 169 +9 %, 196 +28 %): it stays in the library as an option (MI355RT_BND_MINS / MI355RT_BND_MAXS), off by default.
