@@ -708,13 +708,7 @@ def test_u8_hwc_image_layout(renderer):
         renderer.render(0.0, 0.6, 0.3, 1, 0, u8=True, f32=True, flags=L.RT_FLAG_U8_HWC)
 
 
-@pytest.mark.parametrize("S,Ln,P", [(1024, 3, 1), (700, 64, 64), (97, 0, 0),
-                                    (150, 12, 2),     # bundle pre-cull without an anchored table (too many lights for its LDS budget): free-bundle passes only
-                                    (60, 10, 1),      # bundle pre-cull with more lights than it keeps masks for (8)
-                                    (256, 2, 1)])     # the largest scene with candidate masks, clustered
-def test_scene_size_limits_vs_oracle(renderer, oracle, S, Ln, P):
-    """RT_MAX_SPHERES / RT_MAX_LIGHTS / RT_MAX_PLANES: LDS images beyond 64 KiB, no room for the anchored cull
-    table (origin-form culling with clusters only), many lights and planes — bit-exact against the oracle."""
+def _limits_scene_check(r, oracle, S, Ln, P):
     rng = np.random.default_rng(S + Ln)
     sp = np.zeros((7, S), np.float32)
     sp[0:3] = rng.uniform(-6, 8, (3, S)); sp[3] = rng.uniform(0.05, 0.4, S); sp[4:7] = rng.integers(0, 256, (3, S))
@@ -730,15 +724,39 @@ def test_scene_size_limits_vs_oracle(renderer, oracle, S, Ln, P):
     w, h = 48, 40
     cam = Camera((w, h), [-3.0, 0.5, 2.5], [3, -25, 4])
     rg = cam.raygen()
-    renderer.set_scene(sp, li, pl); renderer.set_camera(cam.position, cam.rotation); renderer.set_raygen(w, h, *rg)
+    r.set_scene(sp, li, pl); r.set_camera(cam.position, cam.rotation); r.set_raygen(w, h, *rg)
     for aa in (0, 1):
-        u8, f32 = renderer.render(0.05, 0.5, 0.4, 3, aa, u8=True, f32=True)
+        u8, f32 = r.render(0.05, 0.5, 0.4, 3, aa, u8=True, f32=True)
         ref = oracle.render(w, h, cam.position, cam.rotation, sp, li, pl, 0.05, 0.5, 0.4, 3, aa, raygen=rg, want=("u8", "f32"))
-        assert np.array_equal(u8, ref["u8"]), f"aa={aa}: {(u8 != ref['u8']).any(axis=0).sum()} px differ"
+        assert np.array_equal(u8, ref["u8"]), f"S={S} aa={aa}: {(u8 != ref['u8']).any(axis=0).sum()} px differ"
         assert np.array_equal(f32, ref["f32"])
+    return li, pl
+
+
+@pytest.mark.parametrize("S,Ln,P", [(1024, 3, 1),     # lane-owned traversal without an anchored table (no room in LDS): boxes and origin-form spheres only
+                                    (700, 64, 64), (97, 0, 0), (150, 12, 2), (60, 10, 1), (256, 2, 1),
+                                    (161, 3, 1), (200, 1, 0)])     # around the lane-owned traversal's threshold; 25 clusters = 3 groups + 1
+def test_scene_size_limits_vs_oracle(renderer, oracle, S, Ln, P):
+    """RT_MAX_SPHERES / RT_MAX_LIGHTS / RT_MAX_PLANES: LDS images beyond 64 KiB, no room for the anchored cull
+    table (origin-form culling with clusters only), many lights and planes — bit-exact against the oracle."""
+    li, pl = _limits_scene_check(renderer, oracle, S, Ln, P)
     import python_ray_tracer_amd as pkg
     with pytest.raises(pkg.RenderError):
         renderer.set_scene(np.zeros((7, 1025), np.float32), li, pl)
+
+
+def test_bundle_precull_limits_opt_in(monkeypatch, oracle):
+    """The optional bundle kernels at their own limits: no anchored table (too many lights for its LDS budget: free-bundle
+    passes only), more lights than they keep masks for (8), and the largest scene with candidate masks (256 spheres)."""
+    import python_ray_tracer_amd as pkg
+    for k, v in (("MI355RT_BND_MINS", "8"), ("MI355RT_BND_MAXS", "256"), ("MI355RT_LANES_MINS", "100000")):
+        monkeypatch.setenv(k, v)
+    r = pkg.Renderer(0)
+    try:
+        for S, Ln, P in ((150, 12, 2), (60, 10, 1), (256, 2, 1)):
+            _limits_scene_check(r, oracle, S, Ln, P)
+    finally:
+        r.close()
 
 
 def test_max_depth(renderer, oracle):
