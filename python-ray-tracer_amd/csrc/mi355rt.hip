@@ -42,7 +42,8 @@ struct rt_ctx {
     int bnd_min_spheres = 1 << 30;               // bundle pre-cull: off unless MI355RT_BND_MINS names a size to start it at
     int cluster_min = rt::CLUSTER_MIN;            // scenes with more spheres are stored in clusters (MI355RT_CLUSTER_MINS overrides)
     int bnd_max_spheres = 192;                   // (MI355RT_BND_MAXS overrides; at most rt::BND_MAX_SPHERES)
-    int lanes_primary = 0, lanes_min_spheres = 161;   // MI355RT_LANES_PRIMARY / MI355RT_LANES_MINS (the lane-owned traversal from that size on)
+    int lanes_primary = 1, lanes_min_spheres = 161;   // MI355RT_LANES_MINS: the lane-owned traversal from that size on; MI355RT_LANES_PRIMARY=0: from bounce 1 on only
+                                                      // (primary rays and their shadow rays wave-uniform: +2..3 % since the group level exists)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     int order_group = 0;              // MI355RT_ORDER_GROUP: log2 of the blocks per dispatch group (0..6; 0 = every block on its own)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
