@@ -82,8 +82,8 @@ typedef enum rt_status {
                                   instead of tracing each half-pixel lattice sample once and summing nine per pixel — the
                                   default on the closed-form grid, same bytes, 4 instead of 9 samples per pixel */
 #define RT_FLAG_NO_BUNDLES 64 /* use the plain wave-uniform cull where the library would pick the lane-owned traversal (clustered scenes
-                                with 161 spheres or more) or, if MI355RT_BND_MINS enabled it, the bundle pre-cull (rt_device.h).
-                                Same pixels; for A/B timing. */
+                                with 161 spheres or more; rt_device.h).  Same pixels; for A/B timing.  (The name dates from round 2's
+                                bundle pre-cull, which the flag also switched off; that variant was removed in round 3.) */
 #define RT_FLAG_COUNT_RAYS 16 /* run the counting instantiation of the kernel (slower: registers instead of LDS-parked
                                 state): adds this launch's ray counts to the context's rt_stats.  Same pixels. */
 

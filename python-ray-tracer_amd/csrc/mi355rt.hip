@@ -39,9 +39,7 @@ struct rt_ctx {
     hipEvent_t chunk_ev[RT_RENDER_CHUNKS] = {};
     hipStream_t chunk_stream[RT_RENDER_CHUNKS] = {};
     int chunk_mode = -1;              // -1 = by destination memory type
-    int bnd_min_spheres = 1 << 30;               // bundle pre-cull: off unless MI355RT_BND_MINS names a size to start it at
     int cluster_min = rt::CLUSTER_MIN;            // scenes with more spheres are stored in clusters (MI355RT_CLUSTER_MINS overrides)
-    int bnd_max_spheres = 192;                   // (MI355RT_BND_MAXS overrides; at most rt::BND_MAX_SPHERES)
     int lanes_primary = 1, lanes_min_spheres = 161;   // MI355RT_LANES_MINS: the lane-owned traversal from that size on; MI355RT_LANES_PRIMARY=0: from bounce 1 on only
                                                       // (primary rays and their shadow rays wave-uniform: +2..3 % since the group level exists)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
@@ -159,13 +157,12 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
     return RT_OK;
 }
 
-// instantiations with the bundle pre-cull (MODE 1: flat scenes with rt::BND_MIN_SPHERES spheres or more) and with the
-// lane-owned traversal (MODE 2: clustered scenes); workgroups of 4 only
-template <int MODE> const void *mode_variant(bool aa, bool park, bool lattice)
+// instantiations with the lane-owned traversal (MODE 2: clustered scenes from lanes_min_spheres spheres on); workgroups of
+// 4, register variants only (their LDS image leaves no room for parked state)
+const void *lanes_variant(bool aa, bool lattice)
 {
-    if (lattice) return park ? (const void *)rt::render_kernel<false, true, 4, false, true, MODE> : (const void *)rt::render_kernel<false, false, 4, false, true, MODE>;
-    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4, false, false, MODE> : (const void *)rt::render_kernel<true, false, 4, false, false, MODE>)
-              : (park ? (const void *)rt::render_kernel<false, true, 4, false, false, MODE> : (const void *)rt::render_kernel<false, false, 4, false, false, MODE>);
+    if (lattice) return (const void *)rt::render_kernel<false, false, 4, false, true, 2>;
+    return aa ? (const void *)rt::render_kernel<true, false, 4, false, false, 2> : (const void *)rt::render_kernel<false, false, 4, false, false, 2>;
 }
 
 const void *lattice_variant(bool park, int wpw, bool count = false)     // the plain kernel over the half-pixel lattice (RT_AA_REFERENCE)
@@ -350,19 +347,15 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // 4 waves/SIMD).  Measured against the plain wave-uniform cull of the same clusters
     // (profiles/r02_variant_thresholds.txt): 256 spheres -25 %, 196 spheres -4 % (depth 3) .. -9 % (depth 8), 169 -8 %,
     // but 144 +6 %, 100 +17 %.
-    // The bundle pre-cull (MODE 1) paid on flat scenes and on the clusters round 2 started with (64 spheres -23 %); against
-    // clusters that are compact blocks of neighbours it loses at every size (36 spheres +25 %, 64 +7 %, 100 +7 %, 144 +12 %,
-    // 169 +9 %, 196 +28 %): it stays in the library as an option (MI355RT_BND_MINS / MI355RT_BND_MAXS), off by default.
+    // (Round 2's bundle pre-cull, MODE 1/3, lost against these clusters at every measured size and was removed in round 3:
+    // profiles/r02_variant_thresholds.txt.)
     const bool lanes = ctx->NC > 0 && ctx->S >= ctx->lanes_min_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    const bool bnd = ctx->S >= ctx->bnd_min_spheres && ctx->S <= ctx->bnd_max_spheres && !lanes && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    const int wpw = (image <= 4608 && !count && !bnd && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
+    const int wpw = (image <= 4608 && !count && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
-    const bool bwords = bnd;                                                        // the waves' bundle words in LDS
-    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, bwords);
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
     const bool park = !count && !lanes && lds_park * (24 / wpw) <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, bwords, lanes && k.anchors > 0);
-    const void *fn = bnd ? mode_variant<1>(aa, park, lattice) : lanes ? mode_variant<2>(aa, park, lattice)
-                         : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, lanes && k.anchors > 0);
+    const void *fn = lanes ? lanes_variant(aa, lattice) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -371,10 +364,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         for (int v = 0; v < 4; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(v & 1, (v & 2) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (int v = 0; v < 6; ++v) {
-            RT_HIP(ctx, hipFuncSetAttribute(mode_variant<1>(v & 1, v & 2, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            RT_HIP(ctx, hipFuncSetAttribute(mode_variant<2>(v & 1, v & 2, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
+        for (int v = 0; v < 3; ++v)
+            RT_HIP(ctx, hipFuncSetAttribute(lanes_variant(v == 1, v == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
     }
     if (count) {
@@ -397,7 +388,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const int gshift = ctx->order_group > 0 ? ctx->order_group : 0;
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
-    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (bnd ? 16 : 0) + (lanes ? 32 : 0);
+    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (lanes ? 32 : 0);
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
     if (!fsel) {                                               // a free slot, else the least recently used geometry
@@ -523,9 +514,7 @@ int rt_create(rt_ctx **out, int device)
     ctx->device = device;
     if (const char *e = std::getenv("MI355RT_LANES_PRIMARY")) ctx->lanes_primary = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_LANES_MINS")) ctx->lanes_min_spheres = std::atoi(e);
-    if (const char *e = std::getenv("MI355RT_BND_MINS")) ctx->bnd_min_spheres = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_CLUSTER_MINS")) ctx->cluster_min = std::max(8, std::atoi(e));
-    if (const char *e = std::getenv("MI355RT_BND_MAXS")) ctx->bnd_max_spheres = std::min(std::atoi(e), (int)rt::BND_MAX_SPHERES);
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }

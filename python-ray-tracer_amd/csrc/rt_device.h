@@ -44,9 +44,6 @@
 #ifndef RT_FAST_NORMALIZE
 #define RT_FAST_NORMALIZE 1
 #endif
-#ifndef RT_BND_MAXSIN
-#define RT_BND_MAXSIN 0.5f   // widest bundle (sine of the cone's half-angle) the pre-cull is attempted for
-#endif
 #ifndef RT_OPAQUE_ARGS
 #define RT_OPAQUE_ARGS 1
 #endif
@@ -277,7 +274,6 @@ struct Lds {
     const float *gtab;     // anchors x pad4(supers(NC)) x CULL_STRIDE: the groups' bounding spheres, anchored form
     int NC;
     bool groups;           // a compile-time constant per kernel: test a chunk's group of clusters before its clusters (MODE 2 kernels)
-    unsigned long long *bnd;   // BND kernels: this wave's bundle area (BND_WORDS words): candidate masks + the hit-point ball
     double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
                            // slots 0-2 the running colour of the current sample, 3-5 the incoming direction
                            // during the light loop, 6-8 (AA kernel only) the tap sums — kept out of VGPRs that would stay
@@ -400,194 +396,6 @@ __host__ __device__ inline int padS(int S, int NC) { return NC > 0 ? NC * CLUSTE
 
 
 // ---------------------------------------------------------------------------------------------
-// Bundle pre-cull (scenes with BND_MIN_SPHERES spheres or more).  The per-ray cull above costs 4 (anchored) to 17
-// (origin form) VALU instructions per sphere or cluster bound and RAY; but the 64 rays of a wavefront are a tight
-// bundle (an 8x8 pixel tile's primary rays; the shadow rays from one small patch of surface to one light; the
-// reflections off that patch), and most of the scene is nowhere near it.  So once per query the wave runs ONE pass
-// per 64 spheres (or 64 cluster bounds) with lane = sphere, testing the sphere against a conservative bound of the
-// whole bundle, and the per-ray cull then only looks at the candidates that pass left (typically 0-4 of 64).
-// Like the per-ray cull this never decides a hit: it only removes spheres NO ray of the bundle can hit, so the float64
-// tests that remain, and with them every result bit, are unchanged.
-//
-//  * anchored bundle — lines through a common point A (camera, or the light a shadow query points at) whose
-//    directions lie within angle g of an axis X.  A line through A with direction d hits sphere (c, r) iff the angle
-//    between the line and u = c - A is at most b = asin(r/|u|); line angles obey the triangle inequality, so a hit
-//    implies angle(X, u) <= g + b, i.e. the sphere is culled when |u.X| < |u| cos(g + b) = cos g * T - sin g * r with
-//    T = sqrt(|u|^2 - r^2) the tangent length — which is the tau the anchored cull table already holds (rounded down,
-//    margins subtracted).  Lanes read {A - c, tau} from that table and r^2 from the float32 sphere table.
-//  * free bundle — origins within Ball(C, rho), directions within angle g < 90 deg of X (reflection rays).  With u = c - C,
-//    D = |u|: a forward hit from origin o needs angle(d, c - o) <= asin(r/|c - o|), |c - o| >= D - rho, and
-//    angle(c - o, u) <= asin(rho/D); asin is superadditive on [0,1], so a hit implies
-//    angle(X, u) <= g + asin(s), s = (r + rho)/(D - rho) (required < 1): culled when (u.X)/D < cos g sqrt(1 - s^2) - sin g * s.
-//    (Spheres behind the bundle are culled too: the angle is measured from the forward axis.)
-//  The shadow rays of a hit-point ball toward light A form the anchored bundle X = (C - A)/|C - A|, sin g = rho/|C - A|.
-// Everything is float32 with the bound inflated where it is formed (rho, sin g rounded up by 2^-10 relative plus an
-// absolute slack; cos g rounded down) and 2^-16 taken off the right-hand side — the compared quantities are
-// (sums of three) products of magnitude <= |u| whose rounding errors are below 2^-21 |u|; s is capped at 0.98 so that
-// sqrt(1 - s^2) is well conditioned.  NaNs fail every "cull" comparison: a NaN bundle keeps every sphere.
-// All of it runs in wave-uniform control flow with all 64 lanes executing (lanes without a ray contribute neutral
-// values), between the divergent parts of trace_bounce; the masks wait in the wave's LDS words until the queries read them.
-// ---------------------------------------------------------------------------------------------
-constexpr int BND_MIN_SPHERES = 56;      // below this the per-ray cull of the clustered scene is cheaper than the passes (measured: 49 spheres +1..+5 %, 64 spheres -9 %)
-constexpr int BND_LIGHTS = 8;            // lights with their own candidate masks (further lights: no pre-cull)
-constexpr int CAND_WORDS = 4;            // sphere-level candidate masks: scenes of up to 256 spheres (flat or clustered)
-constexpr int BND_MAX_SPHERES = 64 * CAND_WORDS;
-constexpr int BND_Q = CAND_WORDS + 1;    // LDS words per query: the masks and a validity word
-constexpr int BND_WORDS = BND_Q * (1 + BND_LIGHTS);   // the next closest-hit query, then one query per light
-// The candidates of one query: bit k of word k / 64 = sphere SLOT k might be reached by some ray of the bundle.
-// What a query carries: which of the wave's stored queries its candidates are (q), and their state — the words
-// themselves are read from LDS chunk by chunk where the cull uses them (scalar registers are as scarce as vector ones here).
-struct CandRef {
-    int q;
-    int state;               // 0: no bundle information; 1: candidates stored; 2: stored and EMPTY (no sphere for any lane)
-    bool on;                 // == (state != 0)
-    __device__ __forceinline__ bool none() const { return state == 2; }
-};
-__device__ __forceinline__ CandRef cand_none() { return CandRef{0, 0, false}; }
-
-template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-// max over the wave of non-negative values (0 is neutral); uniform control flow only.  Four DPP steps leave every
-// row of 16 lanes holding its maximum (xor 1, xor 2, mirror of 8, mirror of 16), four readlanes combine the rows.
-__device__ __forceinline__ float wave_max_nonneg(float v)
-{
-    v = __builtin_fmaxf(v, dpp_get<0xB1>(v));             // quad_perm [1,0,3,2]
-    v = __builtin_fmaxf(v, dpp_get<0x4E>(v));             // quad_perm [2,3,0,1]
-    v = __builtin_fmaxf(v, dpp_get<0x141>(v));            // row_half_mirror
-    v = __builtin_fmaxf(v, dpp_get<0x140>(v));            // row_mirror
-    return __builtin_fmaxf(__builtin_fmaxf(readlane_f(v, 0), readlane_f(v, 16)), __builtin_fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
-}
-
-struct Cone { float x, y, z, cosg, sing; bool ok; };
-struct Ball { float x, y, z, rho; bool ok; };
-// wave-uniform values belong in scalar registers (the compiler keeps the result of VALU arithmetic in a VGPR even when
-// every lane holds the same value; registers decide occupancy here)
-__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
-
-// the lane whose ray stands for the bundle's middle: the tile's centre pixel if it takes part, else the first that does
-__device__ __forceinline__ int bundle_lane(unsigned long long part) { return ((part >> 27) & 1ull) ? 27 : (int)__builtin_ctzll(part | (1ull << 63)); }
-
-// smallest cone (axis = one lane's direction) around the unit directions of the lanes in `part`.  |d x X| is the sine
-// of the angle for a direction within 90 degrees of the axis AND for its opposite: a direction with d.X <= 0 is
-// counted as sin = 1, which disqualifies the bundle (lines through an anchor are undirected, but free rays are not).
-__device__ __forceinline__ Cone direction_cone(bool part, const V3 &d)
-{
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(part);
-    const int l = bundle_lane(m);
-    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-    Cone c;
-    c.x = readlane_f(dx, l); c.y = readlane_f(dy, l); c.z = readlane_f(dz, l);
-    const float kx = dy * c.z - dz * c.y, ky = dz * c.x - dx * c.z, kz = dx * c.y - dy * c.x;     // |d x X| = sin(angle)
-    const float dt = __builtin_fmaf(dz, c.z, __builtin_fmaf(dy, c.y, dx * c.x));
-    const float s2 = wave_max_nonneg(part ? (dt > 0.0f ? __builtin_fmaf(kz, kz, __builtin_fmaf(ky, ky, kx * kx)) : 1.0f) : 0.0f);
-    c.sing = uni(__builtin_fmaf(__builtin_sqrtf(s2), 1.0f + 0x1p-10f, 0x1p-20f));                  // rounded up
-    c.cosg = uni(__builtin_sqrtf(__builtin_fmaxf(1.0f - c.sing * c.sing, 0.0f)) * (1.0f - 0x1p-20f));  // rounded down
-    c.ok = (m != 0ull) && (c.sing < RT_BND_MAXSIN);         // directions too far apart: not a bundle
-    return c;
-}
-
-// ball (centre = one lane's point) around the points of the lanes in `part`; slack: float32 rounding of the coordinates
-// and the 0.0002 steps the reference takes off a surface (trace.py:82-83, :110)
-__device__ __forceinline__ Ball point_ball(bool part, const V3 &P)
-{
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(part);
-    const int l = bundle_lane(m);
-    const float px = (float)P.x, py = (float)P.y, pz = (float)P.z;
-    Ball b;
-    b.x = readlane_f(px, l); b.y = readlane_f(py, l); b.z = readlane_f(pz, l);
-    const float ex = px - b.x, ey = py - b.y, ez = pz - b.z;
-    const float d2 = wave_max_nonneg(part ? __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) : 0.0f);
-    const float mag = __builtin_fabsf(b.x) + __builtin_fabsf(b.y) + __builtin_fabsf(b.z);
-    b.rho = uni(__builtin_fmaf(__builtin_sqrtf(d2), 1.0f + 0x1p-10f, __builtin_fmaf(mag, 0x1p-18f, 0.001f)));
-    b.ok = (m != 0ull) && (b.rho == b.rho) && (b.rho < 0x1p60f);
-    return b;
-}
-
-// the anchored bundle of the shadow rays from a ball of hit points toward the point A
-__device__ __forceinline__ Cone cone_toward(const Ball &b, float ax, float ay, float az)
-{
-    const float ux = b.x - ax, uy = b.y - ay, uz = b.z - az;
-    const float d2 = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-    const float inv = __builtin_amdgcn_rsqf(d2);
-    Cone c;
-    c.x = uni(ux * inv); c.y = uni(uy * inv); c.z = uni(uz * inv);
-    c.sing = uni(__builtin_fmaf(b.rho * inv, 1.0f + 0x1p-10f, 0x1p-20f));
-    c.cosg = uni(__builtin_sqrtf(__builtin_fmaxf(1.0f - c.sing * c.sing, 0.0f)) * (1.0f - 0x1p-20f));
-    c.ok = b.ok && (c.sing < RT_BND_MAXSIN);                // (NaN fails)
-    return c;
-}
-
-// One pass, lane = item (sphere or cluster bound) first + lane, items [first, first + count): bit set = candidate.
-// otab: {cx,cy,cz,r2} entries; atab: the anchor's {A - c, tau} entries (anchored form only).
-template <bool ANCH>
-__device__ __forceinline__ unsigned long long bundle_pass(const float *otab, const float *atab, int first, int count,
-                                                          const Cone &k, const Ball &b)
-{
-    const int lane = (int)(threadIdx.x & 63u);
-    const bool in = lane < count;
-    const int i = first + (in ? lane : 0);
-    const f4 c = *reinterpret_cast<lds_cf4 *>((size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const float *)(otab + 4 * i));
-    const float r = __builtin_fmaf(__builtin_sqrtf(c[3]), 1.0f + 0x1p-20f, 0x1p-30f);
-    bool cull;
-    if constexpr (ANCH) {
-        const f4 e = *reinterpret_cast<lds_cf4 *>((size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const float *)(atab + 4 * i));
-        const float lhs = __builtin_fabsf(__builtin_fmaf(e[2], k.z, __builtin_fmaf(e[1], k.y, e[0] * k.x)));
-        const float rhs = __builtin_fmaf(k.cosg, e[3], -(k.sing * r));
-        cull = lhs < rhs - 0x1p-16f * (e[3] + r);
-    } else {
-        const float ux = c[0] - b.x, uy = c[1] - b.y, uz = c[2] - b.z;
-        const float D2 = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-        const float rD = __builtin_amdgcn_rsqf(D2);
-        const float t = D2 * rD - b.rho;                                        // D - rho
-        const float sv = (r + b.rho) * __builtin_amdgcn_rcpf(t) * (1.0f + 0x1p-20f);
-        const float cb = __builtin_sqrtf(__builtin_fmaxf(1.0f - sv * sv, 0.0f));
-        const float lhs = __builtin_fmaf(uz, k.z, __builtin_fmaf(uy, k.y, ux * k.x)) * rD;
-        const float rhs = __builtin_fmaf(k.cosg, cb, -(k.sing * sv));
-        cull = (t > 0.0f) && (sv < 0.98f) && (lhs < rhs - 0x1p-16f);
-    }
-    return __builtin_amdgcn_ballot_w64(in && !cull);
-}
-
-__device__ __forceinline__ void bnd_store(const Lds &lds, int word, unsigned long long v)
-{
-    if ((threadIdx.x & 63u) == 0u) ((volatile unsigned long long *)lds.bnd)[word] = v;
-}
-__device__ __forceinline__ unsigned long long bnd_load(const Lds &lds, int word)
-{
-    const unsigned long long v = ((volatile unsigned long long *)lds.bnd)[word];
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-// The candidates of one query over the sphere slots (flat and clustered scenes alike: the float32 tables are in slot
-// order), stored as query q of the wave's bundle area: 0 = the next closest-hit query, 1 + m = the shadow query of light m.
-// Every mask goes to LDS as soon as its pass has produced it (not a scalar register more than needed stays live).
-template <bool ANCH>
-__device__ __forceinline__ void sphere_candidates(const Lds &lds, int q, int S, int anchor, const Cone &k, const Ball &b)
-{
-    if (!(k.ok && (ANCH || b.ok))) { bnd_store(lds, q * BND_Q + CAND_WORDS, 0ull); return; }     // wave-uniform
-    const int Sp = padS(S, lds.NC);
-    const float *atab = lds.tab + (size_t)anchor * Sp * CULL_STRIDE;
-    bool any = false;
-    for (int first = 0; first < S; first += 64) {
-        const unsigned long long w = bundle_pass<ANCH>(lds.sph32, atab, first, S - first < 64 ? S - first : 64, k, b);
-        bnd_store(lds, q * BND_Q + (first >> 6), w);
-        any = any || (w != 0ull);
-    }
-    bnd_store(lds, q * BND_Q + CAND_WORDS, any ? 1ull : 2ull);
-}
-__device__ __forceinline__ CandRef bnd_cand(const Lds &lds, int q)
-{
-    const int st = __builtin_amdgcn_readfirstlane((int)((volatile unsigned long long *)lds.bnd)[q * BND_Q + CAND_WORDS]);
-    return CandRef{q, st, st != 0};
-}
-__device__ __forceinline__ unsigned long long cand_word(const Lds &lds, const CandRef &c, int k0)   // candidates of slots [k0, k0 + 64)
-{
-    return bnd_load(lds, c.q * BND_Q + ((k0 >> 6) & (CAND_WORDS - 1)));
-}
-
-// ---------------------------------------------------------------------------------------------
 // Slab test of a ray without an anchor (o, R) against a cluster's bounding box, float32, conservative: a certificate
 // that the reference reports a miss for EVERY sphere in the box.
 //   exact geometry: if the half-line o + tR, t >= 0, stays at least d outside the box, it stays d outside every sphere
@@ -680,21 +488,12 @@ __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel
 // flow on scalar masks.
 template <bool ANCH, bool SELF>
 __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S, int anchor, int k0, int n,
-                                                          const RayF &q, int selfj, const CandRef &cand)
+                                                          const RayF &q, int selfj)
 {
     unsigned long long mask = 0ull;
     const int Sp = padS(S, lds.NC);
     lds_cf4 *sbase = pin_lds(ANCH ? lds.tab + ((size_t)anchor * Sp + k0) * CULL_STRIDE : lds.sph32 + 4 * k0);
-    if (cand.on) {                                                            // the bundle's candidates: groups of 4 slots holding one
-        const unsigned long long cw = cand_word(lds, cand, k0) & ((n == 64) ? ~0ull : ((1ull << n) - 1ull));
-        unsigned long long gm = (cw | (cw >> 1) | (cw >> 2) | (cw >> 3)) & 0x1111111111111111ull;
-        while (gm) {
-            const int j = __builtin_ctzll(gm);
-            gm &= gm - 1ull;
-            mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
-        }
-        mask &= cw;
-    } else if (lds.NC > 0) {
+    if (lds.NC > 0) {
         const int NCp = pad4(lds.NC), c0 = k0 / CLUSTER, nc = (n + CLUSTER - 1) / CLUSTER;
         if (ANCH && lds.groups) {                                             // the chunk's 8 clusters are one group: is any lane's ray near it at all?
                                                                               // (the kernels of the large scenes only: 196 spheres -3 %, 256 -4 %; 36-100 spheres +0.4..+1.6 %)
@@ -725,7 +524,7 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
 }
 
 __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, int anchor, int k0, int n,
-                                                        const V3 &o, const V3 &R, float extent2, int self, const CandRef &cd)
+                                                        const V3 &o, const V3 &R, float extent2, int self)
 {
     RayF q = make_rayf_dir(R);
     if (anchor >= 0) {
@@ -735,12 +534,12 @@ __device__ __forceinline__ unsigned long long cull_mask(const Lds &lds, int S, i
             const float *cs = lds.sph32 + 4 * self;
             const bool self_culled = cand ? cull_origin(f4{cs[0], cs[1], cs[2], cs[3]}, q) : false;
             if (__builtin_amdgcn_ballot_w64(self_culled) != 0ull)
-                return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1, cd);
+                return cull_mask_t<true, true>(lds, S, anchor, k0, n, q, self_culled ? self - k0 : -1);
         }
-        return cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1, cd);
+        return cull_mask_t<true, false>(lds, S, anchor, k0, n, q, -1);
     }
     add_origin(q, o, extent2);
-    return cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1, cd);
+    return cull_mask_t<false, false>(lds, S, anchor, k0, n, q, -1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1052,18 +851,14 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
-template <int MODE>      // 0: wave-uniform cull; 1: + bundle pre-cull (cand); 2: lane-owned traversal of a clustered scene; 3: both (lane-owned where there is no bundle)
+template <int MODE>      // 0: wave-uniform cull; 2: lane-owned traversal of a clustered scene (1 and 3 were round 2's bundle pre-cull, removed)
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
-                                            double &t_out, int &idx_out, int &type_out, const CandRef &cand)
+                                            double &t_out, int &idx_out, int &type_out)
 {
-    constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = opaque(p.P);
-    // the bundle pre-cull left no sphere any lane's ray could reach: the sphere part — including the re-normalised
-    // direction only it uses — is skipped (wave-uniform)
-    const int S = (BND && cand.none()) ? 0 : p.S;
-    V3 R{0.0, 0.0, 0.0};
-    double a = 1.0;
-    if (!BND || S > 0) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
+    const int S = p.S;
+    const V3 R = renormalize_unit(d);                         // R == normalize(d), intersections.py:13
+    const double a = dot3(R, R);
 #if RT_PREFILTER
     const int canchor = (opaque(p.anchors) > 0) ? anchor : -1;
 #endif
@@ -1071,7 +866,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     int bidx = -1;
     // lane-owned traversal for the rays without a common anchor (bounce 1 on), where the wave's rays have parted;
     // the primary rays of a tile travel together: the wave-uniform cull below is cheaper for them
-    if (MODE >= 2 && lds.NC > 0 && !cand.on && (canchor < 0 || p.lanes_primary)) {
+    if (MODE >= 2 && lds.NC > 0 && (canchor < 0 || p.lanes_primary)) {
         if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig);
         else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig);
     } else
@@ -1080,7 +875,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #if RT_PREFILTER
       unsigned long long mask;
       // the float32 ray is rebuilt per chunk so that it is not live during the float64 phase
-      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, -1, cand);
+      mask = cull_mask(lds, S, canchor, k0, n, o, R, p.extent2, -1);
       mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);       // padding slots certify themselves, except to a NaN ray
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
@@ -1115,24 +910,23 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 // anchor = cull-table index of the light the ray points at; self = index of the sphere the ray
 // starts on (-1: a plane), whose miss is certified by the origin-form "behind" test.
 template <int MODE>
-__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, const CandRef &cand, bool lanes = true)
+__device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor, int self, bool lanes = true)
 {
-    constexpr bool BND = MODE == 1 || MODE == 3;
     const int P = opaque(p.P);
-    const int S = (BND && cand.none()) ? 0 : p.S;                           // no candidate sphere for any lane (wave-uniform)
+    const int S = p.S;
     V3 R{0.0, 0.0, 0.0};
     double a = 1.0;
     // RT_LAZY_RENORM: the float32 cull runs on d itself (within 2^-52 of R: the same float32 values up to the
     // rounding the margins already budget for) and R, a are formed only if some lane's mask is not empty
     constexpr bool LAZY = RT_LAZY_RENORM && MODE == 0;
-    if (!LAZY && (!BND || S > 0)) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
+    if (!LAZY) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
     bool a_sane = (a > 0.999999 && a < 1.000001);
     bool haveR = !LAZY;
     bool occ = false;
 #if RT_PREFILTER
     const int canchor = (opaque(p.anchors) > 0) ? anchor : -1;
 #endif
-    if (MODE >= 2 && lds.NC > 0 && !cand.on && lanes) {
+    if (MODE >= 2 && lds.NC > 0 && lanes) {
         occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self) : lanes_any<false>(lds, p, -1, o, R, a, self);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
@@ -1140,7 +934,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
-      mask = cull_mask(lds, S, canchor, k0, n, o, LAZY ? d : R, p.extent2, self, cand);
+      mask = cull_mask(lds, S, canchor, k0, n, o, LAZY ? d : R, p.extent2, self);
       mask &= (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
@@ -1199,7 +993,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
-    if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type, cand_none());   // :53 (idle lanes masked off)
+    if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type);   // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
     if (alive) {
@@ -1237,7 +1031,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             cnt.shadow(true, k > 0.0);
             if (k > 0.0) {
                 // (the shadow rays of the primary hits still travel together: wave-uniform cull unless p.lanes_primary)
-                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, cand_none(), anchor != 0 || p.lanes_primary);
+                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, anchor != 0 || p.lanes_primary);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -1252,108 +1046,12 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 }
 
 
-// trace_bounce for the BND instantiations (scenes with BND_MIN_SPHERES spheres or more): the same per-lane arithmetic,
-// cut into its divergent parts so that the bundle passes between them run with all 64 lanes:
-//   closest hit (candidates prepared by the previous bounce / by sample() for the primary rays)
-//   | hit point, normal                       — lanes that hit
-//   | ball of the hit points -> one candidate pass per light       — whole wave
-//   | light loop, reflection                   — lanes that hit
-//   | cone of the reflected directions -> candidates of the next closest-hit query      — whole wave
-template <bool PARK, int WGT, bool COUNT, int MODE>
-__device__ __forceinline__ void trace_bounce_bnd(const Lds &lds, const KParams &p, bool &alive, int anchor,
-                                                 V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt, bool last)
-{
-    const int S = p.S, P = p.P, L = opaque(p.L);
-    rgb = V3{0.0, 0.0, 0.0};
-    double t = 999.0; int idx = -1, type = HIT_NONE;
-    cnt.closest(alive);
-    {
-        const CandRef cc = bnd_cand(lds, 0);
-        if (alive) closest_hit<MODE>(lds, p, o, d, anchor, t, idx, type, cc);    // :53
-    }
-    alive = alive && (type != HIT_NONE);                                      // :56-57
-    cnt.hit(alive);
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;                   // wave-uniform
-    V3 Pt{0.0, 0.0, 0.0}, N{0.0, 0.0, 0.0};
-    int coff = 0, self = -1;
-    Park3<PARK, WGT> dpark(lds.acc, 1);
-    if (alive) {
-        Pt = V3{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                 // :60
-        coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : opaque(S) * SPH_STRIDE + idx * PL_STRIDE + 12;
-        V3 bN;
-        if (type == HIT_SPHERE) {                                             // :63-66
-            const double *g = lds.recs() + idx * SPH_STRIDE;
-            N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});
-            bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
-        } else {                                                              // :68-71
-            const double *g = lds.recs() + opaque(S) * SPH_STRIDE + idx * PL_STRIDE;
-            N = V3{g[6], g[7], g[8]};
-            bN = V3{g[9], g[10], g[11]};
-        }
-        Pt = V3{Pt.x + bN.x, Pt.y + bN.y, Pt.z + bN.z};                       // :82-83
-        self = (type == HIT_SPHERE) ? idx : -1;
-        dpark.set(d);
-    }
-    // ---- whole wave: the hit points' ball and, per light, the spheres / clusters some shadow ray might reach
-    const Ball ball = point_ball(alive, Pt);
-    const int nl = L < BND_LIGHTS ? L : BND_LIGHTS;
-    const double *lt = lds.recs() + opaque(S) * SPH_STRIDE + opaque(P) * PL_STRIDE;
-    for (int m = 0; m < nl; ++m) {
-        const double *g = lt + m * LT_STRIDE;
-        const Cone k = cone_toward(ball, (float)g[0], (float)g[1], (float)g[2]);
-        if (p.anchors > 0) sphere_candidates<true>(lds, 1 + m, S, 1 + m, k, ball);
-        else sphere_candidates<false>(lds, 1 + m, S, 0, Cone{-k.x, -k.y, -k.z, k.cosg, k.sing, k.ok}, ball);   // the rays run from the ball toward the light
-    }
-    if (alive) {
-        volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.recs() + coff;
-        V3 colr{0.0, 0.0, 0.0};
-        if constexpr (!PARK) colr = V3{lds.recs()[coff], lds.recs()[coff + 1], lds.recs()[coff + 2]};
-        auto col = [&](int c) -> double { if constexpr (PARK) return colp[c]; else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z); };
-        rgb = V3{p.amb * col(0), p.amb * col(1), p.amb * col(2)};             // :77
-        for (int m = 0; m < L; ++m) {                                         // :86-102
-            const double *g = lt + m * LT_STRIDE;
-            const V3 Ld = normalize3(V3{g[0] - Pt.x, g[1] - Pt.y, g[2] - Pt.z});
-            const double k = p.lamb * dot3(Ld, N);                            // :99
-            cnt.shadow(true, k > 0.0);
-            if (k > 0.0) {
-                const CandRef cs = m < nl ? bnd_cand(lds, 1 + m) : cand_none();
-                const bool occluded = any_hit<MODE>(lds, p, Pt, Ld, 1 + m, self, cs, anchor != 0 || p.lanes_primary);
-                if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
-            }
-        }
-        d = dpark.get();
-        const double c2 = -2.0 * dot3(d, N);                                  // common.py:113-120
-        const V3 Rd = renormalize_unit(V3{d.x + c2 * N.x, d.y + c2 * N.y, d.z + c2 * N.z});
-        o = V3{Pt.x + 0.0002 * Rd.x, Pt.y + 0.0002 * Rd.y, Pt.z + 0.0002 * Rd.z};   // :110
-        d = Rd;
-    }
-    // ---- whole wave: the reflected rays leave the ball within a cone -> candidates of the next closest-hit query
-    if (!last) {
-        const Cone kr = direction_cone(alive, d);
-        sphere_candidates<false>(lds, 0, S, 0, kr, ball);
-    }
-}
-
-// the primary rays of a sample: lines through the camera (anchor 0) within a cone -> candidates of the first query
-__device__ __forceinline__ void primary_bundle(const Lds &lds, const KParams &p, bool alive, const V3 &d)
-{
-    const Cone k = direction_cone(alive, d);
-    if (p.anchors > 0) sphere_candidates<true>(lds, 0, p.S, 0, k, Ball{0.0f, 0.0f, 0.0f, 0.0f, false});
-    else {
-        const float cx = (float)p.cam_o[0], cy = (float)p.cam_o[1], cz = (float)p.cam_o[2];
-        const Ball b{cx, cy, cz, (__builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz)) * 0x1p-18f + 0x1p-20f, true};
-        sphere_candidates<false>(lds, 0, p.S, 0, k, b);
-    }
-}
-
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
-template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 1 bundle pre-cull, 2 lane-owned traversal
+template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 2 lane-owned traversal
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
-    constexpr bool BND = MODE == 1 || MODE == 3;
     Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
-    if constexpr (BND) primary_bundle(lds, p, alive, d);
     for (int b = 0; b <= p.depth; ++b) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;                                   // wave-uniform exit
         if constexpr (COUNT) {                                                // lane utilisation per bounce: waves entering, lanes alive
@@ -1364,8 +1062,6 @@ __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool aliv
             }
         }
         V3 rgb;
-        if constexpr (BND) trace_bounce_bnd<PARK, WGT, COUNT, MODE>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt, b == p.depth);
-        else
         trace_bounce<PARK, WGT, COUNT, MODE == 2>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
@@ -1479,11 +1175,10 @@ __host__ __device__ inline size_t table_floats(int S, int NC, int anchors, bool 
     const TableLayout t = table_layout(S, NC, anchors);
     return lanes ? t.total_lanes : t.total;
 }
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool bnd = false, bool lanes = false)
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool lanes = false)
 {
     return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
-           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16 +   // + workgroup cost/arrival words
-           (bnd ? (size_t)(wgt / 64) * BND_WORDS * sizeof(unsigned long long) : 0);          // + the waves' bundle words
+           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16;   // + workgroup cost/arrival words
 }
 
 // The float32 cull tables (exact sphere table for the origin form; {A-c, tau} per anchor and sphere; the same two
@@ -1599,13 +1294,10 @@ template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, int
 #ifndef RT_W_AAPARK
 #define RT_W_AAPARK 7   // 72 VGPRs with a few spills (76 B/lane of scratch) still beat 5 waves/SIMD without: -9 %
 #endif
-#ifndef RT_W_BND
-#define RT_W_BND 6      // the bundle variants keep a few more values live between the divergent parts
-#endif
 #ifndef RT_W_LANES
 #define RT_W_LANES 4    // lane-owned traversal (clustered scenes: the LDS image bounds the occupancy at about 4 anyway) wants registers
 #endif
-__global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PARK) ? RT_W_BND : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
+__global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
@@ -1621,7 +1313,6 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
     float *ctab = sph32 + tl.ctab;                     // anchors x NCp entries
     float *cbox = sph32 + tl.cbox;                     // NCp boxes
     unsigned *wgstat = reinterpret_cast<unsigned *>(sph32 + (LANES ? tl.total_lanes : tl.total));   // {cycles, waves done}
-    unsigned long long *bnd = reinterpret_cast<unsigned long long *>(wgstat + 4) + (threadIdx.x >> 6) * BND_WORDS;   // BND: this wave's words
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
         // used to be computed here, by every workgroup: 3 % of the frame's VALU instructions and a second barrier.)
@@ -1637,7 +1328,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (MODE == 1 && PA
     // two-wave workgroups serve the small flat scenes only (the host sends every clustered scene to workgroups of 4): with
     // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
     // register optimum)
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, MODE >= 2, bnd, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, MODE >= 2, accum};
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a

@@ -203,12 +203,14 @@ def test_c2_eight_slabs_in_place_full_frame(renderer):
         renderer.free(d8); renderer.free(d32)
 
 
-def test_bundle_precull_opt_in(monkeypatch, oracle):
-    """The bundle pre-cull (MODE 1 kernels) is off by default since the clusters became compact blocks; MI355RT_BND_MINS turns
-    it on from that many spheres.  Still the same pixels: config 4's golden lattice, and random scenes of 40..190 spheres
-    (flat below 33, clustered above) against the oracle, with and without the 9-tap mode."""
+@pytest.mark.parametrize("lanes_mins", [None, "30"])
+def test_random_scenes_every_cull_variant(monkeypatch, oracle, lanes_mins):
+    """Flat scenes (two- and four-wave workgroups), clustered scenes under the wave-uniform cull and under the lane-owned
+    traversal (default from 161 spheres; MI355RT_LANES_MINS=30 sends every clustered scene of this test through it): config 4's
+    golden lattice, and random scenes of 12..190 spheres against the oracle, with and without the 9-tap mode."""
     import python_ray_tracer_amd as pkg
-    monkeypatch.setenv("MI355RT_BND_MINS", "8")
+    if lanes_mins:
+        monkeypatch.setenv("MI355RT_LANES_MINS", lanes_mins)
     r = pkg.Renderer(0)
     try:
         g = load_frame("c4_s64_d5_sub32")
@@ -745,12 +747,11 @@ def test_scene_size_limits_vs_oracle(renderer, oracle, S, Ln, P):
         renderer.set_scene(np.zeros((7, 1025), np.float32), li, pl)
 
 
-def test_bundle_precull_limits_opt_in(monkeypatch, oracle):
-    """The optional bundle kernels at their own limits: no anchored table (too many lights for its LDS budget: free-bundle
-    passes only), more lights than they keep masks for (8), and the largest scene with candidate masks (256 spheres)."""
+def test_wave_uniform_cull_at_large_scenes(monkeypatch, oracle):
+    """MI355RT_LANES_MINS=100000 keeps the wave-uniform cluster cull for scenes the library would hand to the lane-owned
+    traversal: no anchored table (too many lights for its LDS budget: origin-form certificates only), many lights, 256 spheres."""
     import python_ray_tracer_amd as pkg
-    for k, v in (("MI355RT_BND_MINS", "8"), ("MI355RT_BND_MAXS", "256"), ("MI355RT_LANES_MINS", "100000")):
-        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("MI355RT_LANES_MINS", "100000")
     r = pkg.Renderer(0)
     try:
         for S, Ln, P in ((150, 12, 2), (60, 10, 1), (256, 2, 1)):

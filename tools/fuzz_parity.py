@@ -35,7 +35,7 @@ while time.time() - t0 < a.seconds:
         nrm = rng.normal(size=(3, P))
         if kind == 3: nrm = np.eye(3)[:, rng.integers(0, 3, P)] * rng.choice([-1.0, 1.0], P)
         pl[3:6] = nrm / np.linalg.norm(nrm, axis=0, keepdims=True); pl[6:9] = rng.integers(0, 256, (3, P))
-    Ln = int(rng.integers(0, 6)) if rng.integers(0, 8) else int(rng.integers(6, 14))     # now and then more lights than the bundle pre-cull keeps masks for
+    Ln = int(rng.integers(0, 6)) if rng.integers(0, 8) else int(rng.integers(6, 14))     # now and then many lights (the anchored cull table then outgrows its LDS budget)
     li = (rng.uniform(-6, 8, (3, Ln)) * scale).astype(np.float32)
     if kind == 4 and S and Ln: li[:, 0] = sp[0:3, 0]          # a light at a sphere centre
     w, h = int(rng.integers(9, 70)), int(rng.integers(9, 70))

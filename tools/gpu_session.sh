@@ -27,9 +27,7 @@ for step in "$@"; do
     hostpath) timeout -k 10 300 python tools/host_path_rate.py > $OUT/hostpath.log 2>&1 || exit 1; cat $OUT/hostpath.log ;;
     ab4)      timeout -k 10 300 python tools/ab_bench.py python-ray-tracer_amd/libmi355rt.so python-ray-tracer_amd/libmi355rt.so:64 --workload c4_3840x2160_s64_d5 --rounds 8 --launches 10 > $OUT/ab4.log 2>&1 || exit 1; cat $OUT/ab4.log ;;
     ab5)      timeout -k 10 400 python tools/ab_bench.py python-ray-tracer_amd/libmi355rt.so python-ray-tracer_amd/libmi355rt.so:64 --workload c5_7680x4320_s256_d8 --rounds 5 --launches 3 > $OUT/ab5.log 2>&1 || exit 1; cat $OUT/ab5.log ;;
-    bdebug)   timeout -k 10 300 python tools/bundle_debug.py > $OUT/bdebug.log 2>&1; cat $OUT/bdebug.log ;;
-    bdebug5)  timeout -k 10 300 python tools/bundle_debug.py --workload c5_7680x4320_s256_d8 --scale 8 > $OUT/bdebug5.log 2>&1; cat $OUT/bdebug5.log ;;
-    thresholds) : > $OUT/thresholds.txt; for wl in x_1920x1080_s16_d3 x_1920x1080_s25_d3 x_1920x1080_s36_d3 x_3840x2160_s36_d5 x_1920x1080_s49_d3 x_3840x2160_s49_d5 c4_3840x2160_s64_d5 x_3840x2160_s100_d5 x_3840x2160_s144_d5 x_3840x2160_s169_d5 x_1920x1080_s196_d3 x_7680x4320_s196_d8 x_3840x2160_s256_d5 c5_7680x4320_s256_d8; do for env in "" "MI355RT_BND_MINS=1 MI355RT_BND_MAXS=256 MI355RT_LANES_MINS=100000" "MI355RT_LANES_MINS=97"; do echo "== $wl  [$env]  selection under that environment (none = default; BND_* = bundle pre-cull wherever it can run; LANES_MINS=97 = lane-owned traversal for every clustered scene) vs RT_FLAG_NO_BUNDLES (plain wave-uniform cull)" >> $OUT/thresholds.txt; env $env timeout -k 10 200 python tools/ab_bench.py python-ray-tracer_amd/libmi355rt.so python-ray-tracer_amd/libmi355rt.so:64 --workload $wl --rounds 5 --launches 5 2>&1 | grep -E "median|identical" | sed 's/"sha_u8.*"vs_first"/"vs_first"/' >> $OUT/thresholds.txt || exit 1; done; done; cat $OUT/thresholds.txt ;;
+    thresholds) : > $OUT/thresholds.txt; for wl in x_1920x1080_s16_d3 x_1920x1080_s25_d3 x_1920x1080_s36_d3 x_3840x2160_s36_d5 x_1920x1080_s49_d3 x_3840x2160_s49_d5 c4_3840x2160_s64_d5 x_3840x2160_s100_d5 x_3840x2160_s144_d5 x_3840x2160_s169_d5 x_1920x1080_s196_d3 x_7680x4320_s196_d8 x_3840x2160_s256_d5 c5_7680x4320_s256_d8; do for env in "" "MI355RT_LANES_MINS=97"; do echo "== $wl  [$env]  selection under that environment (none = default; BND_* = bundle pre-cull wherever it can run; LANES_MINS=97 = lane-owned traversal for every clustered scene) vs RT_FLAG_NO_BUNDLES (plain wave-uniform cull)" >> $OUT/thresholds.txt; env $env timeout -k 10 200 python tools/ab_bench.py python-ray-tracer_amd/libmi355rt.so python-ray-tracer_amd/libmi355rt.so:64 --workload $wl --rounds 5 --launches 5 2>&1 | grep -E "median|identical" | sed 's/"sha_u8.*"vs_first"/"vs_first"/' >> $OUT/thresholds.txt || exit 1; done; done; cat $OUT/thresholds.txt ;;
     balance)  timeout -k 10 400 python tools/slab_balance.py > $OUT/balance.log 2>&1 || exit 1; cat $OUT/balance.log ;;
     trace_aa) mkdir -p $OUT/trace_aa && cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_aa -- python3 $ROOT/examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/trace_aa.log 2>&1 || exit 1; cd $ROOT; cp $(find $OUT/trace_aa -name "*kernel_stats.csv" | head -1) $OUT/aa_kernel_stats.csv; rm -rf $OUT/trace_aa; tail -1 $OUT/trace_aa.log; head -4 $OUT/aa_kernel_stats.csv ;;
     aa)       timeout -k 10 200 python examples/render_png.py --size 1000x1000 --depth 4 --aa --frames 200 --out $OUT/aa.png > $OUT/aa.log 2>&1 || exit 1; cat $OUT/aa.log ;;
