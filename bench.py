@@ -35,7 +35,16 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-ROUND = "r02"           # profiles/traffic_<ROUND>.json, profiles/valu_<ROUND>.json (written by tools/profile_round.py)
+ROUND = "r03"           # profiles/traffic_<ROUND>[_<workload>].json, profiles/valu_<ROUND>[_<workload>].json (tools/profile_round.py --stamp)
+PRICES = "r03_valu_prices.json"   # cycles per wave-instruction and class, measured by tools/valu_prices.hip on an MI355X
+CLOCK_HZ = 2.4e9        # peak engine clock: a kernel cannot run faster than its priced instructions take at this clock
+SIMDS = 1024            # 256 CUs x 4
+# which measured class prices which rocprofv3 op-mix counter (SQ_INSTS_VALU_<KEY>)
+PRICE_CLASS = {"add_f64": "v_add_f64", "mul_f64": "v_mul_f64", "fma_f64": "v_fma_f64", "trans_f64": "v_rsq_f64",
+               "add_f32": "v_add_f32", "mul_f32": "v_mul_f32", "fma_f32": "v_fma_f32", "trans_f32": "v_rcp_f32",
+               "cvt": "v_cvt_f32_f64", "int32": "v_and_b32", "int64": "v_lshlrev_b64"}
+UNCATEGORISED_FLOOR = "v_mov_b32"                   # the cheapest VALU class measured: prices the lower bound
+UNCATEGORISED_TYPICAL = "v_cmp_lt_f64_e64->sgpr"    # compares, selects, readlanes, 64-bit moves all measure 4.1-4.2 cycles
 
 
 def cpu_baseline(wl, rays_per_frame, min_wall_s=2.5):
@@ -71,6 +80,29 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+def issue_bound(v, prices, waves_per_simd):
+    """Prices a kernel's measured VALU op mix (wave-instructions per launch and counter class) with the measured cycles
+    per wave-instruction at the kernel's occupancy.  The instructions the counters do not classify (compares, selects,
+    moves, readlanes, DPP ...) are priced at the cheapest measured class for the BOUND (a launch cannot take less) and
+    at the price of a compare/select for the ESTIMATE."""
+    col = "w7" if waves_per_simd >= 6 else "w4"
+    cyc = {c["class"]: c[col]["cycles_simd_span"] for c in prices["classes"]}
+    mix = v["op_mix_wave_instructions"]
+    total = v["valu_wave_instructions_per_launch"]
+    cycles, counted, table = 0.0, 0, {}
+    for key, cls in PRICE_CLASS.items():
+        n = mix.get(key, 0)
+        counted += n
+        cycles += n * cyc[cls]
+        table[key] = {"wave_instructions": n, "cycles_each": cyc[cls], "priced_as": cls}
+    unc = max(0, total - counted)
+    table["uncategorised"] = {"wave_instructions": unc, "cycles_each_bound": cyc[UNCATEGORISED_FLOOR], "priced_as_bound": UNCATEGORISED_FLOOR,
+                              "cycles_each_estimate": cyc[UNCATEGORISED_TYPICAL], "priced_as_estimate": UNCATEGORISED_TYPICAL}
+    lo = (cycles + unc * cyc[UNCATEGORISED_FLOOR]) / (SIMDS * CLOCK_HZ) * 1e3
+    est = (cycles + unc * cyc[UNCATEGORISED_TYPICAL]) / (SIMDS * CLOCK_HZ) * 1e3
+    return lo, est, table, col
 
 
 def stamped(path, so_sha):
@@ -211,7 +243,7 @@ def main():
     # step's kernel was launched on (torch.cuda.Event on a stream object records on THAT stream, not on torch's
     # current one).  Launches of one stream run back to back, so the gap between consecutive events of a stream is
     # the duration of one launch as rocprofv3's kernel trace sees it; the gaps between consecutive completions over
-    # all streams give the frame periods (over windows of NS completions).  NS launches are in flight at a time.
+    # all streams give the frame periods (over windows of completions, below).  NS launches are in flight at a time.
     step_events = not a.no_step_events
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
@@ -244,9 +276,10 @@ def main():
             last[s_] = evs[i]
             done.append(ev0[0].elapsed_time(evs[i]))     # completion time of step i on a common clock
         # NS launches are in flight together and complete in clumps, so the period of a frame is taken over a window
-        # of 2 NS consecutive completions: (t[i] - t[i - 2 NS]) / (2 NS)
+        # of W consecutive completions: (t[i] - t[i - W]) / W, W = max(16 NS, 32)
         done.sort()
-        W = 2 * NS if len(done) > 2 * NS else NS
+        # (round 2 used 2 NS: a clump of completions could then read as a period below the kernel's own issue bound)
+        W = min(max(16 * NS, 32), max(1, len(done) - 1))          # (--steps 20: one window over all of them)
         periods = [(done[i] - done[i - W]) / W for i in range(W, len(done))]
     if not use_gather:
         frame = pipe.last_slab()[:, :ws]
@@ -278,7 +311,8 @@ def main():
         achieved = alg_bytes / (kernel_eff * 1e-3) / 1e9
         so_sha = hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()
         headline1 = world == 1 and name == workloads.HEADLINE
-        tr = stamped(os.path.join(REPO, "profiles", f"traffic_{ROUND}.json"), so_sha) if headline1 else None
+        suffix = "" if name == workloads.HEADLINE else f"_{name}"
+        tr = stamped(os.path.join(REPO, "profiles", f"traffic_{ROUND}{suffix}.json"), so_sha) if world == 1 else None
         traffic = tr.get("hbm_bytes_per_launch") if tr else None
         frame_host = frame.cpu().numpy()
         check = None
@@ -370,17 +404,40 @@ def main():
                                  "(about 15 B and ~2 kflop per pixel): the HBM fraction is reported because BASELINE.json's "
                                  "north_star asks for it, not because HBM limits this kernel"},
         }
-        # The bound that actually limits this kernel: VALU instruction issue.  Per-launch counts from the rocprofv3
-        # op-mix pass of THIS library build (profiles/valu_<round>.json carries the build's SHA-256; another build -> null).
-        v = stamped(os.path.join(REPO, "profiles", f"valu_{ROUND}.json"), so_sha) if headline1 else None
-        if v:
-            out["valu"] = {"fp64_flop_per_launch": v["fp64_flop_per_launch"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"],
-                           "achieved_fp64_tflops": round(v["fp64_flop_per_launch"] / (kernel_eff * 1e-3) / 1e12, 3),
-                           "peak_fp64_vector_tflops": 78.6, "frac": round(v["fp64_flop_per_launch"] / (kernel_eff * 1e-3) / 78.6e12, 4),
-                           # every VALU wave-instruction occupies its SIMD for 4 cycles (64 lanes over 16): 1024 SIMDs at 2.4 GHz
-                           "issue_bound_ms": round(v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) * 1e3, 5),
-                           "issue_frac": round(v["valu_wave_instructions_per_launch"] * 4 / (1024 * 2.4e9) / (kernel_eff * 1e-3), 4),
-                           "note": v["note"]}
+        # The bound that actually limits this kernel: VALU instruction issue.  Per-launch counts from the rocprofv3 op-mix
+        # pass of THIS library build (profiles/valu_<round>[_<workload>].json carries the build's SHA-256; another build ->
+        # null), priced with the cycles per wave-instruction tools/valu_prices.hip measured (profiles/r03_valu_prices.json;
+        # MI355X_MICROARCH.md, "Per-instruction cycle constants": wave64 v_fma_f32 2 cycles with co-resident waves, 4 alone).
+        v = stamped(os.path.join(REPO, "profiles", f"valu_{ROUND}{suffix}.json"), so_sha) if world == 1 else None
+        ppath = os.path.join(REPO, "profiles", PRICES)
+        if v and os.path.exists(ppath):
+            info = r.kernel_info()
+            waves = 7 if (name == workloads.HEADLINE) else 4         # launch bounds of the instantiation the workload selects
+            lo, est, table, col = issue_bound(v, json.load(open(ppath)), waves)
+            util = v.get("lane_utilisation") or 1.0
+            flop = v["fp64_flop_wave_level_x64"] * util                 # wave-level count x 64 lanes x live-lane fraction
+            out["valu"] = {"valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"],
+                           "salu_wave_instructions_per_launch": v.get("salu_wave_instructions_per_launch"),
+                           "lane_utilisation": v.get("lane_utilisation"),
+                           "fp64_flop_per_launch": int(flop),
+                           "achieved_fp64_tflops": round(flop / (kernel_eff * 1e-3) / 1e12, 3),
+                           "peak_fp64_vector_tflops": 78.6, "frac_of_fp64_peak": round(flop / (kernel_eff * 1e-3) / 78.6e12, 4),
+                           "issue_bound_ms": round(lo, 5), "issue_frac": round(lo / kernel_eff, 4),
+                           "issue_estimate_ms": round(est, 5), "issue_estimate_frac": round(est / kernel_eff, 4),
+                           "prices": {"file": f"profiles/{PRICES}", "column": col, "clock_ghz": CLOCK_HZ / 1e9, "simds": SIMDS, "classes": table},
+                           "kernel_vgprs": info.get("vgprs"),
+                           "note": "issue_bound_ms = sum over classes of (wave-instructions x measured cycles per wave-instruction at this "
+                                   "occupancy) / (1024 SIMDs x 2.4 GHz), unclassified instructions at the cheapest measured price: the launch "
+                                   "cannot be shorter at this instruction count; issue_estimate_ms prices them as compares/selects (4.1 "
+                                   "cycles).  issue_frac = issue_bound_ms / time per launch (<= 1 by construction of a bound).  "
+                                   "The scalar unit (one per CU, ~1 instruction per cycle) is the second bound: "
+                                   "salu_wave_instructions_per_launch / (256 x 2.4 GHz)."}
+            if v.get("salu_wave_instructions_per_launch"):
+                out["valu"]["salu_bound_ms"] = round(v["salu_wave_instructions_per_launch"] * 1.09 / (256 * CLOCK_HZ) * 1e3, 5)
+            # the "reference-equivalent" flop figure of the frame (the work the reference's formulation
+            # would do for the same queries: 18 S + 14 P per scene query, 51 + 24 L per shaded hit)
+            if traced:
+                out["valu"]["reference_equivalent_flop_per_frame"] = int(rays_per_frame * (18 * S + 14 * P) + traced["hits"] * (51 + 24 * L))
         else:
             out["valu"] = None
         if world == 1 and not a.no_cpu_baseline:

@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--sets", default="sq1,sq2,sq3,sq4,fetch,write")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--stamp", action="store_true")
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--flags", type=int, default=0)
     a = ap.parse_args()
     out = os.path.join(REPO, "gpurun_out", f"prof_{a.tag}")
@@ -114,24 +114,29 @@ def main():
         from python_ray_tracer_amd import _lib
         sha = hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()
         g = lambda k: summary.get(k, {}).get("mean_per_launch")     # noqa: E731
+        suffix = f"_{a.workload}" if a.workload else ""     # bench.py looks the constants up by round and workload
         if g("WRITE_SIZE") is not None and g("FETCH_SIZE") is not None:
             wr, fe = g("WRITE_SIZE") * 1024.0, g("FETCH_SIZE") * 1024.0
             json.dump({"so_sha256": sha, "source": f"gpurun_out/prof_{a.tag} (tools/profile_round.py): rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes",
                        "WRITE_SIZE_KB_per_launch": g("WRITE_SIZE"), "FETCH_SIZE_KB_per_launch_raw": g("FETCH_SIZE"),
                        "correction": "FETCH_SIZE doubled (gfx950 reports half of streamed read bytes); WRITE_SIZE as is",
-                       "hbm_bytes_per_launch": int(wr + 2 * fe)}, open(os.path.join(out, f"traffic_{a.round}.json"), "w"), indent=1)
+                       "hbm_bytes_per_launch": int(wr + 2 * fe)}, open(os.path.join(out, f"traffic_{a.round}{suffix}.json"), "w"), indent=1)
         if g("SQ_INSTS_VALU") is not None and g("SQ_INSTS_VALU_FMA_F64") is not None:
             add, mul, fma = g("SQ_INSTS_VALU_ADD_F64"), g("SQ_INSTS_VALU_MUL_F64"), g("SQ_INSTS_VALU_FMA_F64")
             json.dump({"so_sha256": sha, "source": f"gpurun_out/prof_{a.tag} (tools/profile_round.py): rocprofv3 --pmc SQ_INSTS_VALU_*",
                        "valu_wave_instructions_per_launch": int(g("SQ_INSTS_VALU")),
                        "salu_wave_instructions_per_launch": int(g("SQ_INSTS_SALU") or 0),
-                       "fp64_flop_per_launch": int(64 * (g("SQ_INSTS_VALU_FLOPS_FP64") or (add + mul + 2 * fma))),
+                       "lds_wave_instructions_per_launch": int(g("SQ_INSTS_LDS") or 0),
+                       "kernel": summary.get("_kernel"),
+                       # live lanes per VALU wave-instruction (SQ_THREAD_CYCLES_VALU counts lane-quad-cycles, SQ_ACTIVE_INST_VALU quad-cycles)
+                       "lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4)
+                                           if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU") else None,
+                       "fp64_flop_wave_level_x64": int(64 * (g("SQ_INSTS_VALU_FLOPS_FP64") or (add + mul + 2 * fma))),
                        "op_mix_wave_instructions": {k[len("SQ_INSTS_VALU_"):].lower(): int(v["mean_per_launch"]) for k, v in summary.items()
                                                     if k.startswith("SQ_INSTS_VALU_")},
-                       "note": "non-fusable float64 (the reference never fuses multiply-add); every VALU wave-instruction occupies its SIMD "
-                               "for ~4 cycles whatever its type: the kernel is bound by VALU instruction issue (issue_frac, priced at the "
-                               "2.4 GHz peak engine clock), not by fp64 throughput or HBM"},
-                      open(os.path.join(out, f"valu_{a.round}.json"), "w"), indent=1)
+                       "note": "non-fusable float64 (the reference never fuses multiply-add); bench.py prices this op mix with the measured "
+                               "cycles per wave-instruction of profiles/r03_valu_prices.json (tools/valu_prices.hip)"},
+                      open(os.path.join(out, f"valu_{a.round}{suffix}.json"), "w"), indent=1)
     print("done", out, flush=True)
 
 

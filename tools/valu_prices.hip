@@ -31,7 +31,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum Cls {
-    FMA_F64, MUL_F64, ADD_F64, FMA_F32, MUL_F32, ADD_F32, CMP_F64_SGPR, CMP_F32_SGPR, CMP_F32_VCC, CNDMASK_B32, CNDMASK_VCC_ONCE, CNDMASK_E64_SGPR, CNDMASK_AFTER_VCMP, MOV_B32, READLANE,
+    FMA_F64, MUL_F64, ADD_F64, FMA_F32, MUL_F32, ADD_F32, CMP_F64_SGPR, CMP_F32_SGPR, CMP_F32_VCC, CNDMASK_B32, CNDMASK_VCC_ONCE, CNDMASK_E64_SGPR, CNDMASK_E64_VCC, CNDMASK_E32_FDATA, CNDMASK_AFTER_VCMP, MIX_FMA64_CND_E32, MIX_FMA64_CND_E64, PAT_CC6F, PAT_CFC5F, PAT_CFFC4F, PAT_VCC6F_E32, PAT_VCC6F_E64, PAT_CCCCC3F, DIV_FMAS_F64, DIV_SCALE_F64, DIV_FIXUP_F64, FMAC_F64, LDEXP_F64, MOV_B64, MOV_B32, READLANE,
     CVT_F32_F64, CVT_F64_F32, RSQ_F64, RCP_F64, SQRT_F64, RNDNE_F64, RCP_F32, MIN3_F32, MAX_F64, AND_B32, ADD_U32, LSHL_B64, MOV_DPP,
     MIX_F64_F32, DS_READ_B128_UNIFORM, DS_READ_B128_LANE, DS_READ_B64_UNIFORM, DS_WRITE_B64_LANE,
     SALU_AND_B64, SALU_CMP_ADDC, EMPTY_LOOP, NCLS
@@ -39,14 +39,19 @@ enum Cls {
 static const char *cls_name[NCLS] = {
     "v_fma_f64", "v_mul_f64", "v_add_f64", "v_fma_f32", "v_mul_f32", "v_add_f32", "v_cmp_lt_f64_e64->sgpr", "v_cmp_lt_f32_e64->sgpr",
     "v_cmp_lt_f32_e32 (vcc)", "v_cndmask_b32 (vcc written by s_mov once per 32)", "v_cndmask_b32 (vcc written once, outside the loop)",
-    "v_cndmask_b32_e64 (mask in an SGPR pair written outside the loop)", "v_cmp_lt_f32_e32 vcc + 7 v_cndmask_b32 (per instruction of the 8)", "v_mov_b32", "v_readlane_b32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64", "v_rndne_f64",
+    "v_cndmask_b32_e64 (mask in an SGPR pair written outside the loop)", "v_cndmask_b32_e64 (VOP3 encoding, mask = vcc written outside the loop)", "v_cndmask_b32_e32 vcc, operands hold normal float32 values", "v_cmp_lt_f32_e32 vcc + 7 v_cndmask_b32 (per instruction of the 8)",
+    "mix: 6 v_fma_f64 + 2 v_cndmask_b32_e32 vcc (per instruction of the 8)", "mix: 6 v_fma_f64 + 2 v_cndmask_b32_e64 sgpr pair (per instruction of the 8)",
+    "pattern: 2 v_cndmask_b32_e32 back to back + 6 v_fma_f64 (per instruction of the 8)", "pattern: cndmask_e32, fma, cndmask_e32, 5 fma (per instruction of the 8)",
+    "pattern: cndmask_e32, 2 fma, cndmask_e32, 4 fma (per instruction of the 8)", "pattern: v_cmp_gt_f64_e32 vcc, 2 v_cndmask_b32_e32, 5 fma (per instruction of the 8)",
+    "pattern: v_cmp_gt_f64_e64 sgpr, 2 v_cndmask_b32_e64, 5 fma (per instruction of the 8)", "pattern: 5 v_cndmask_b32_e32 back to back + 3 fma (per instruction of the 8)",
+    "v_div_fmas_f64 (reads vcc)", "v_div_scale_f64 (writes vcc)", "v_div_fixup_f64", "v_fmac_f64_e32", "v_ldexp_f64", "v_mov_b64", "v_mov_b32", "v_readlane_b32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64", "v_rndne_f64",
     "v_rcp_f32", "v_min3_f32", "v_max_f64", "v_and_b32", "v_add_u32", "v_lshlrev_b64", "v_mov_b32_dpp",
     "mix: v_fma_f64 / v_fma_f32 alternating", "ds_read_b128 (wave-uniform address)", "ds_read_b128 (16 B per lane, consecutive)",
     "ds_read_b64 (wave-uniform address)", "ds_write_b64 (8 B per lane, consecutive)",
     "s_and_b64", "s_cmp_lg_u64 + s_addc_u32 (pair = 2 instructions)", "empty loop (per iteration / 32)"};
 static const char *cls_counter[NCLS] = {    // the rocprofv3 SQ counter(s) that count this class
     "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32",
-    "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_CVT",
+    "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "-", "-", "-", "-", "-", "-", "-", "-", "uncategorised", "uncategorised", "uncategorised", "SQ_INSTS_VALU_FMA_F64", "uncategorised", "uncategorised", "uncategorised", "uncategorised", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_CVT",
     "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_TRANS_F64", "uncategorised", "SQ_INSTS_VALU_TRANS_F32", "uncategorised", "uncategorised",
     "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "uncategorised", "-", "SQ_INSTS_LDS", "SQ_INSTS_LDS", "SQ_INSTS_LDS", "SQ_INSTS_LDS",
     "SQ_INSTS_SALU", "SQ_INSTS_SALU", "-"};
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(256) void price_kernel(Rec *out, double *sink, int 
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     __syncthreads();
-    if constexpr (CLS == CNDMASK_VCC_ONCE) asm volatile("s_mov_b64 vcc, 0x55" ::: "vcc");
-    if constexpr (CLS == CNDMASK_E64_SGPR) asm volatile("s_mov_b64 s[40:41], 0x55" ::: "s40", "s41");
+    if constexpr (CLS == CNDMASK_VCC_ONCE || CLS == CNDMASK_E64_VCC || CLS == CNDMASK_E32_FDATA || CLS == MIX_FMA64_CND_E32 || CLS == PAT_CC6F || CLS == PAT_CFC5F || CLS == PAT_CFFC4F || CLS == PAT_CCCCC3F || CLS == DIV_FMAS_F64) asm volatile("s_mov_b64 vcc, 0x55" ::: "vcc");
+    if constexpr (CLS == CNDMASK_E64_SGPR || CLS == MIX_FMA64_CND_E64) asm volatile("s_mov_b64 s[40:41], 0x55" ::: "s40", "s41");
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
@@ -118,7 +123,46 @@ __global__ __launch_bounds__(256) void price_kernel(Rec *out, double *sink, int 
 #define CE(j) "v_cndmask_b32_e64 %" #j ", %8, %" #j ", s[40:41]\n"
 #define CE8 CE(0) CE(1) CE(2) CE(3) CE(4) CE(5) CE(6) CE(7)
             asm volatile(CE8 CE8 CE8 CE8 : U8 : "v"(usel) : SG);
-        } else if constexpr (CLS == CNDMASK_AFTER_VCMP) {
+        } else if constexpr (CLS == CNDMASK_E64_VCC) {
+#define CW(j) "v_cndmask_b32_e64 %" #j ", %8, %" #j ", vcc\n"
+#define CW8 CW(0) CW(1) CW(2) CW(3) CW(4) CW(5) CW(6) CW(7)
+            asm volatile(CW8 CW8 CW8 CW8 : U8 : "v"(usel) : "vcc");
+        } else if constexpr (CLS == CNDMASK_E32_FDATA) {
+            asm volatile(I2("v_cndmask_b32") I2("v_cndmask_b32") I2("v_cndmask_b32") I2("v_cndmask_b32") : F8 : "v"(xf) : "vcc");
+        } else if constexpr (CLS == PAT_CC6F) {
+            asm volatile("v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : "vcc");
+        } else if constexpr (CLS == PAT_CFC5F) {
+            asm volatile("v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : "vcc");
+        } else if constexpr (CLS == PAT_CFFC4F) {
+            asm volatile("v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" "v_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\n" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : "vcc");
+        } else if constexpr (CLS == PAT_VCC6F_E32) {
+            asm volatile("v_cmp_gt_f64 vcc, %0, %1\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" "v_cmp_gt_f64 vcc, %0, %1\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" "v_cmp_gt_f64 vcc, %0, %1\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" "v_cmp_gt_f64 vcc, %0, %1\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : "vcc");
+        } else if constexpr (CLS == PAT_VCC6F_E64) {
+            asm volatile("v_cmp_gt_f64_e64 s[40:41], %0, %1\nv_cndmask_b32_e64 %6, %10, %6, s[40:41]\nv_cndmask_b32_e64 %7, %10, %7, s[40:41]\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" "v_cmp_gt_f64_e64 s[40:41], %0, %1\nv_cndmask_b32_e64 %6, %10, %6, s[40:41]\nv_cndmask_b32_e64 %7, %10, %7, s[40:41]\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" "v_cmp_gt_f64_e64 s[40:41], %0, %1\nv_cndmask_b32_e64 %6, %10, %6, s[40:41]\nv_cndmask_b32_e64 %7, %10, %7, s[40:41]\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" "v_cmp_gt_f64_e64 s[40:41], %0, %1\nv_cndmask_b32_e64 %6, %10, %6, s[40:41]\nv_cndmask_b32_e64 %7, %10, %7, s[40:41]\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\n" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : SG);
+        } else if constexpr (CLS == PAT_CCCCC3F) {
+            asm volatile("v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\n" "v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\n" "v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\n" "v_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_cndmask_b32 %7, %10, %7\nv_cndmask_b32 %6, %10, %6\nv_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\n" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : "vcc");
+        } else if constexpr (CLS == MIX_FMA64_CND_E32) {
+#define M32 "v_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_cndmask_b32 %6, %10, %6\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\nv_cndmask_b32 %7, %10, %7\n"
+            asm volatile(M32 M32 M32 M32 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : "vcc");
+        } else if constexpr (CLS == MIX_FMA64_CND_E64) {
+#define M64 "v_fma_f64 %0, %8, %9, %0\nv_fma_f64 %1, %8, %9, %1\nv_fma_f64 %2, %8, %9, %2\nv_cndmask_b32_e64 %6, %10, %6, s[40:41]\nv_fma_f64 %3, %8, %9, %3\nv_fma_f64 %4, %8, %9, %4\nv_fma_f64 %5, %8, %9, %5\nv_cndmask_b32_e64 %7, %10, %7, s[40:41]\n"
+            asm volatile(M64 M64 M64 M64 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(u[0]), "+v"(u[1]) : "v"(x), "v"(y), "v"(usel) : SG);
+        } else if constexpr (CLS == DIV_FMAS_F64) { asm volatile(I3("v_div_fmas_f64") I3("v_div_fmas_f64") I3("v_div_fmas_f64") I3("v_div_fmas_f64") : D8 : "v"(x), "v"(y) : "vcc"); }
+        else if constexpr (CLS == DIV_SCALE_F64) {
+#define DS_(j) "v_div_scale_f64 %" #j ", vcc, %8, %9, %8\n"
+#define DS8 DS_(0) DS_(1) DS_(2) DS_(3) DS_(4) DS_(5) DS_(6) DS_(7)
+            asm volatile(DS8 DS8 DS8 DS8 : D8 : "v"(x), "v"(y) : "vcc");
+        } else if constexpr (CLS == DIV_FIXUP_F64) { asm volatile(I3("v_div_fixup_f64") I3("v_div_fixup_f64") I3("v_div_fixup_f64") I3("v_div_fixup_f64") : D8 : "v"(x), "v"(y)); }
+        else if constexpr (CLS == FMAC_F64) {
+#define FM(j) "v_fmac_f64_e32 %" #j ", %8, %9\n"
+#define FM8 FM(0) FM(1) FM(2) FM(3) FM(4) FM(5) FM(6) FM(7)
+            asm volatile(FM8 FM8 FM8 FM8 : D8 : "v"(x), "v"(y));
+        } else if constexpr (CLS == LDEXP_F64) {
+#define LX(j) "v_ldexp_f64 %" #j ", %" #j ", %8\n"
+#define LX8 LX(0) LX(1) LX(2) LX(3) LX(4) LX(5) LX(6) LX(7)
+            asm volatile(LX8 LX8 LX8 LX8 : D8 : "v"(ush));
+        } else if constexpr (CLS == MOV_B64) { asm volatile(I1("v_mov_b64") I1("v_mov_b64") I1("v_mov_b64") I1("v_mov_b64") : D8 : "v"(x)); }
+        else if constexpr (CLS == CNDMASK_AFTER_VCMP) {
 #define CA "v_cmp_lt_f32 vcc, %9, %10\n" "v_cndmask_b32 %0, %8, %0\nv_cndmask_b32 %1, %8, %1\nv_cndmask_b32 %2, %8, %2\nv_cndmask_b32 %3, %8, %3\nv_cndmask_b32 %4, %8, %4\nv_cndmask_b32 %5, %8, %5\nv_cndmask_b32 %6, %8, %6\n"
             asm volatile(CA CA CA CA : U8 : "v"(usel), "v"(xf), "v"(yf) : "vcc");
         } else if constexpr (CLS == MOV_B32) { asm volatile(I1("v_mov_b32") I1("v_mov_b32") I1("v_mov_b32") I1("v_mov_b32") : U8 : "v"(usel)); }
