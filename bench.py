@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--workload", default=None, help="one of python_ray_tracer_amd.workloads.CONFIGS")
     ap.add_argument("--streams", type=int, default=3, help="streams the frames are queued on round-robin (1 = strictly serial)")
     ap.add_argument("--frames-per-gather", type=int, default=8, help="N > 1: frames whose slabs travel to rank 0 in one gather")
+    ap.add_argument("--frames-per-launch", type=int, default=8, help="frames one kernel launch renders (rt_render_sequence); with a gather: = --frames-per-gather; 0 = one Python call and one launch per frame, as in round 2")
+    ap.add_argument("--gather", choices=("u8", "f32"), default="u8", help="N > 1: assemble the uint8 frames only, or the float32 pre-clip planes as well (a second gather per batch)")
+    ap.add_argument("--no-dynamic", action="store_true", help="skip the moving-camera pass behind the timed region (dynamic)")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 exchange structure on one GPU (world-size-1 RCCL group)")
     ap.add_argument("--preheat-ms", type=float, default=300.0, help="wall time of real frames rendered before the warm-up (clock ramp)")
     ap.add_argument("--no-step-events", action="store_true", help="do not record one HIP event per step (drops the per-step statistics)")
@@ -190,15 +193,18 @@ def main():
     if a.force_gather and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
-    F = max(1, a.frames_per_gather) if use_gather else 1
-    frame = None
+    batched = a.frames_per_launch > 0
+    F = max(1, a.frames_per_gather) if use_gather else max(1, a.frames_per_launch)
+    frame = frame32 = None
 
-    def on_frames(first, frames, count):                # rank 0: a batch of assembled (3,w,h) frames
-        nonlocal frame
+    def on_frames(first, frames, count, frames32=None):  # the batch's root: a batch of assembled (3,w,h) frames
+        nonlocal frame, frame32
         frame = frames[count - 1]
+        frame32 = frames32[count - 1] if frames32 is not None else None
     pipe = SequencePipeline(w, h, ws, dev, dist if use_gather else None, dst=0, streams=NS, frames_per_gather=F,
                             want_f32=True, on_frames=on_frames, bounds=bounds if use_gather else None,
-                            rotate_root=(a.gather_root == "rotate" and world > 1))
+                            rotate_root=(a.gather_root == "rotate" and world > 1), frames_per_launch=F,
+                            gather_f32=(a.gather == "f32"))
     PS = pipe.plane_stride                              # slabs are stored padded to the widest rank's width
     assert all(pipe.stream_handle(i) for i in range(NS)), "expected non-default stream handles"
 
@@ -209,6 +215,40 @@ def main():
         if k not in ptrs:
             ptrs[k] = (u8.data_ptr(), f32.data_ptr())
         r.render_device(params, x0, x1, ptrs[k][0], ptrs[k][1], PS, stream)
+
+    # A batch of F frames = ONE call of rt_render_sequence = one kernel launch (the frames share a grid): the host pays one
+    # Python call and one launch per F frames.  The whole-batch tensors live as long as the pipeline, so their id() is a
+    # safe key; slices (a partly filled batch) are looked up directly.
+    batch_ptrs = {id(t): (t.data_ptr(), f.data_ptr()) for t, f in zip(pipe.u8, pipe.f32)}
+    torch_stream = {hnd: st for hnd, st in zip(pipe.handles, pipe.streams)}
+    record = []                                         # (event, stream index, frames) per launch while recording
+
+    def launch_seq(u8b, f32b, nf, stream):
+        p8, p32 = batch_ptrs.get(id(u8b)) or (u8b.data_ptr(), f32b.data_ptr())
+        r.render_sequence(params, x0, x1, nf, p8, p32, PS, 3 * PS, None, (stream,), nf)
+
+    def submit(nframes, events=None):
+        """Queue nframes frames; with `events`, one HIP event behind every launch, on the stream it was launched on."""
+        if not batched:
+            for _ in range(nframes):
+                i = pipe.n
+                pipe.submit(launch)
+                if events is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(pipe.streams[i % NS])
+                    events.append((ev, i % NS, 1))
+            return
+        if events is None:
+            pipe.submit_frames(launch_seq, nframes)
+            return
+        left = nframes
+        while left > 0:                                 # batch by batch, so that every launch gets its event
+            room = F - pipe.n % F
+            for si, nf in pipe.submit_frames(launch_seq, min(left, room)):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(pipe.streams[si])
+                events.append((ev, si, nf))
+            left -= min(left, room)
 
     for _ in range(2):                                  # setup, like the uploads above: the first two launches of a geometry
         launch(pipe.u8v[0][0], pipe.f32v[0][0], pipe.stream_handle(0))
@@ -221,8 +261,7 @@ def main():
     if a.preheat_ms > 0:
         cal = 4 * F * NS
         tc = time.perf_counter()
-        for _ in range(cal):
-            pipe.submit(launch)
+        submit(cal)
         pipe.drain()
         per = (time.perf_counter() - tc) / cal
         n = int(max(0.0, a.preheat_ms * 1e-3 - (time.perf_counter() - t_pre)) / max(per, 1e-6))
@@ -230,57 +269,65 @@ def main():
         if world > 1:
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
         n = min(int(cnt[0]), 2_000_000)
-        for _ in range(n):
-            pipe.submit(launch)
+        submit(n)
         pipe.drain()
         preheat_frames = cal + n
     preheat_ms = (time.perf_counter() - t_pre) * 1e3
 
-    for i in range(a.warmup):
-        pipe.submit(launch)
+    submit(a.warmup)
     pipe.drain()
-    # One HIP event per launch stream in front of the timed region and one behind every step, on the stream the
-    # step's kernel was launched on (torch.cuda.Event on a stream object records on THAT stream, not on torch's
-    # current one).  Launches of one stream run back to back, so the gap between consecutive events of a stream is
-    # the duration of one launch as rocprofv3's kernel trace sees it; the gaps between consecutive completions over
-    # all streams give the frame periods (over windows of completions, below).  NS launches are in flight at a time.
+    # One HIP event per launch stream in front of the timed region and one behind every LAUNCH, on the stream the
+    # launch was made on (torch.cuda.Event on a stream object records on THAT stream, not on torch's current one).
+    # Launches of one stream run back to back, so the gap between consecutive events of a stream is the duration of one
+    # launch as rocprofv3's kernel trace sees it (a launch renders `frames_per_launch` frames); the gaps between completions
+    # over all streams give the frame periods (over windows of completions, below).  NS launches are in flight at a time.
     step_events = not a.no_step_events
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)] if step_events else []
+    evs = [] if step_events else None
     fence()
     t0 = time.perf_counter()
-    first_pos = pipe.n
     for s_ in range(NS):
         ev0[s_].record(pipe.streams[s_])
-    for i in range(a.steps):
-        pipe.submit(launch)
-        if step_events:
-            evs[i].record(pipe.streams[(first_pos + i) % NS])
+    submit(a.steps, evs)
     t_submitted = time.perf_counter()
     for s_ in range(NS):
         ev1[s_].record(pipe.streams[s_])
-    pipe.drain()                                        # every one of the K frames is assembled on rank 0
+    pipe.drain()                                        # every one of the K frames is assembled on its root
     fence()
     dt = time.perf_counter() - t0
-    launches = [sum(1 for i in range(first_pos, first_pos + a.steps) if i % NS == s_) for s_ in range(NS)]
-    spans = [ev0[s_].elapsed_time(ev1[s_]) / launches[s_] for s_ in range(NS) if launches[s_]]
-    kernel_ms = sum(spans) / max(len(spans), 1)
-    per_launch, periods = [], []
-    if step_events:
+    per_launch, periods, launch_frames = [], [], []
+    kernel_ms, frames_per_launch_avg = 0.0, float(F if batched else 1)
+    if step_events and evs:
         last = {s_: ev0[s_] for s_ in range(NS)}
         done = []
-        for i in range(a.steps):
-            s_ = (first_pos + i) % NS
-            per_launch.append(last[s_].elapsed_time(evs[i]))
-            last[s_] = evs[i]
-            done.append(ev0[0].elapsed_time(evs[i]))     # completion time of step i on a common clock
-        # NS launches are in flight together and complete in clumps, so the period of a frame is taken over a window
-        # of W consecutive completions: (t[i] - t[i - W]) / W, W = max(16 NS, 32)
+        for ev, si, nf in evs:
+            per_launch.append(last[si].elapsed_time(ev))
+            launch_frames.append(nf)
+            last[si] = ev
+            done.append((ev0[0].elapsed_time(ev), nf))   # completion time of the launch on a common clock
+        kernel_ms = sum(per_launch) / len(per_launch)
+        frames_per_launch_avg = sum(launch_frames) / len(launch_frames)
+        # NS launches are in flight together and complete in clumps, so the period of a frame is taken over windows of
+        # consecutive completions that hold at least 32 frames (all of them under --steps 20):
+        # (t[i] - t[j]) / (frames completed after j up to i).  (Round 2 used 2 NS frames: a clump of completions could then
+        # read as a period below the kernel's own issue bound.)
         done.sort()
-        # (round 2 used 2 NS: a clump of completions could then read as a period below the kernel's own issue bound)
-        W = min(max(16 * NS, 32), max(1, len(done) - 1))          # (--steps 20: one window over all of them)
-        periods = [(done[i] - done[i - W]) / W for i in range(W, len(done))]
+        need = min(max(16 * NS, 32), max(1, sum(nf for _, nf in done[1:])))
+        j, acc = 0, 0
+        for i in range(1, len(done)):
+            acc += done[i][1]
+            while acc - done[j + 1][1] >= need and j + 1 < i:
+                j += 1
+                acc -= done[j][1]
+            if acc >= need:
+                periods.append((done[i][0] - done[j][0]) / acc)
+    else:
+        launches = [0] * NS
+        pos = 0
+        spans = [ev0[s_].elapsed_time(ev1[s_]) for s_ in range(NS)]
+        nl = max(1, -(-a.steps // (F if batched else 1)))
+        kernel_ms = sum(spans) / max(len(spans), 1) / max(1.0, nl / NS)
     if not use_gather:
         frame = pipe.last_slab()[:, :ws]
     elif pipe.rotate_root:                              # the last batch was assembled on its own root: rank 0 checks it
@@ -289,10 +336,16 @@ def main():
         dist.broadcast(buf, src=last_root)
         frame = buf
 
-    t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, kernel_ms_max = float(t[0]), float(t[1])
+    mine = torch.tensor([dt, kernel_ms, (t_submitted - t0) / a.steps * 1e3, float(x0), float(x1)], dtype=torch.float64, device=dev)
+    per_rank = None
+    if world > 1:                                       # every rank's own numbers travel to rank 0's line
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [{"rank": q, "columns": [int(v[3]), int(v[4])], "wall_ms_per_step": round(float(v[0]) / a.steps * 1e3, 5),
+                     "launch_ms": round(float(v[1]), 5), "host_submit_ms_per_step": round(float(v[2]), 5)} for q, v in enumerate(allv)]
+        dt, kernel_ms_max = max(float(v[0]) for v in allv), max(float(v[1]) for v in allv)
+    else:
+        kernel_ms_max = kernel_ms
 
     if rank == 0:
         rays = wl["rays"]
@@ -306,8 +359,10 @@ def main():
         # algorithmic HBM bytes of one launch of this rank's kernel: float32 RGB planes (12 B/px) + uint8
         # frame (3 B/px) stored once, scene + camera read once (DESIGN.md "Measurement")
         S, L, P = wl["spheres"].shape[1], wl["lights"].shape[1], wl["planes"].shape[1]
-        alg_bytes = ws * h * 15 + 4 * (7 * S + 3 * L + 9 * P) + 96
-        kernel_eff = kernel_ms_max / NS                  # NS launches are in flight at a time
+        alg_bytes = ws * h * 15 + 4 * (7 * S + 3 * L + 9 * P) + 96      # per frame
+        fpl = frames_per_launch_avg                      # frames one launch of the timed region rendered (mean)
+        alg_bytes_launch = alg_bytes * fpl
+        kernel_eff = kernel_ms_max / NS / fpl            # time per frame: NS launches of fpl frames each are in flight at a time
         achieved = alg_bytes / (kernel_eff * 1e-3) / 1e9
         so_sha = hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()
         headline1 = world == 1 and name == workloads.HEADLINE
@@ -354,7 +409,45 @@ def main():
             serial = {"launches": ns, "kernel_ms": round(mean, 5), "kernel_ms_median": round(statistics.median(durs), 5),
                       "kernel_ms_min": round(min(durs), 5), "achieved": round(alg_bytes / (mean * 1e-3) / 1e9, 3),
                       "frac": round(alg_bytes / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                      "note": "one stream, launches strictly back to back: achieved = algorithmic_bytes / kernel_ms, the plain formula"}
+                      "note": "one stream, ONE frame per launch, launches strictly back to back (round 2's serial mode): achieved = "
+                              "algorithmic_bytes_per_frame / kernel_ms, the plain formula"}
+
+        # -- the same frames with a camera that moves with EVERY frame (README.md:23 "real-time display"; scene/camera.py:8-16):
+        # one rt_render_sequence call per chunk of frames carries their cameras; one launch per frame, round-robin on the
+        # streams; the dispatch order measured under an earlier camera is kept and refreshed every MI355RT_REMEASURE frames,
+        # the cull tables are rebuilt per camera position on the launching stream.  Same timing discipline as the main
+        # region (fence, K steps, fence); never `value`.
+        dynamic = None
+        if world == 1 and not a.no_dynamic:
+            chunk = 8 * NS                              # frames per call; frame i of a chunk always lands on stream i % NS
+            cams = workloads.camera_path(chunk * 16)    # the path repeats; consecutive frames always differ
+            dyn8 = torch.empty((chunk, 3, ws, h), dtype=torch.uint8, device=dev)
+            dyn32 = torch.empty((chunk, 3, ws, h), dtype=torch.float32, device=dev)
+            handles = tuple(pipe.handles)
+
+            def dyn(nframes, start=0):
+                done_ = 0
+                while done_ < nframes:
+                    nf = min(chunk, nframes - done_)
+                    c0 = ((start + done_) // chunk % 16) * chunk
+                    r.render_sequence(params, x0, x1, nf, dyn8.data_ptr(), dyn32.data_ptr(), ws * h, 3 * ws * h,
+                                      cams[c0:c0 + nf], handles, 0)
+                    done_ += nf
+            dyn(max(a.warmup, 4 * chunk))
+            fence()
+            td = time.perf_counter()
+            dyn(a.steps, start=chunk)
+            td_sub = time.perf_counter()
+            fence()
+            dyn_ms = (time.perf_counter() - td) / a.steps * 1e3
+            st = r.stats()
+            dynamic = {"ms_per_step": round(dyn_ms, 5), "ratio_to_static": round(dyn_ms / ms_per_step, 4),
+                       "host_submit_ms_per_step": round((td_sub - td) / a.steps * 1e3, 5), "streams": NS,
+                       "camera": "python_ray_tracer_amd.workloads.camera_path: position, pitch, yaw and roll change with every frame",
+                       "note": "one launch per frame (every frame has its own camera and cull tables); frames bit-equal to the oracle: "
+                               "tests/test_gpu_parity.py::test_moving_camera_sequence"}
+            r.set_camera(cam.position, cam.rotation)    # back to the static camera for what follows
+            del dyn8, dyn32
 
         # -- the host-buffer entry point (what an unchanged main.py sees: launch + copy_to_host); never `value`
         host_path = None
@@ -385,24 +478,36 @@ def main():
             "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
             "traced_mrays_per_s": round(traced["total_traced"] / (dt / a.steps) / 1e6, 2) if traced else None,
             "rays_traced": traced,
+            "value_is": "reference-algorithm scene queries (closest-hit + shadow, SURVEY.md section 8d 'total') answered per second; "
+                        "traced_mrays_per_s counts only the queries the kernel traces (it skips shadow queries whose answer the "
+                        "reference discards, trace.py:101)",
+            "frames_per_launch": round(fpl, 3), "launches": len(per_launch) if per_launch else None,
+            "per_rank": per_rank,
             "frame_matches_reference_sha256": check,
             "slab_balance": balance,
+            "dynamic": dynamic,
             "host_path_ms": host_path,
             "library_sha256": so_sha,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "rt::render_kernel", "kernel_ms": round(kernel_ms_max, 5), "launches_in_flight": NS,
-                         "kernel_ms_per_launch_effective": round(kernel_eff, 5), "algorithmic_bytes": alg_bytes,
-                         "per_launch": {"achieved": round(alg_bytes / (kernel_ms_max * 1e-3) / 1e9, 3),
-                                        "frac": round(alg_bytes / (kernel_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                        "note": "plain formula on the overlapped launches of the timed region: algorithmic_bytes / kernel_ms"},
+                         "frames_per_launch": round(fpl, 3), "algorithmic_bytes_per_frame": alg_bytes,
+                         "algorithmic_bytes": int(alg_bytes_launch), "ms_per_frame_effective": round(kernel_eff, 5),
+                         "per_launch": {"achieved": round(alg_bytes_launch / (kernel_ms_max * 1e-3) / 1e9, 3),
+                                        "frac": round(alg_bytes_launch / (kernel_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                        "note": "plain formula on the launches of the timed region as they ran (launches_in_flight of them "
+                                                "side by side): algorithmic_bytes / kernel_ms"},
+                         "wall": {"achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 3),
+                                  "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                  "note": "algorithmic_bytes_per_frame / ms_per_step: what a clock around the whole timed region sees"},
                          "serial": serial,
-                         "note": "kernel_ms = mean duration of one launch (HIP event pair per stream / launches on it; what "
-                                 "rocprofv3's kernel trace shows); launches_in_flight of them overlap, so achieved = "
-                                 "launches_in_flight x algorithmic_bytes / kernel_ms (= bytes per frame period); `per_launch` and "
-                                 "`serial` follow from the plain formula.  float64 VALU-bound by construction "
-                                 "(about 15 B and ~2 kflop per pixel): the HBM fraction is reported because BASELINE.json's "
-                                 "north_star asks for it, not because HBM limits this kernel"},
+                         "note": "kernel_ms = mean duration of one launch (HIP event behind every launch, on its stream; what "
+                                 "rocprofv3's kernel trace shows); a launch renders frames_per_launch frames (algorithmic_bytes = "
+                                 "frames_per_launch x algorithmic_bytes_per_frame) and launches_in_flight launches run side by side, so "
+                                 "achieved = launches_in_flight x algorithmic_bytes / kernel_ms (= bytes per frame period); with "
+                                 "--streams 1 that IS the plain formula, and `per_launch`, `wall` and `serial` follow from it at any "
+                                 "setting.  float64 VALU-bound by construction (about 15 B and ~2 kflop per pixel): the HBM fraction is "
+                                 "reported because BASELINE.json's north_star asks for it, not because HBM limits this kernel"},
         }
         # The bound that actually limits this kernel: VALU instruction issue.  Per-launch counts from the rocprofv3 op-mix
         # pass of THIS library build (profiles/valu_<round>[_<workload>].json carries the build's SHA-256; another build ->
@@ -442,6 +547,14 @@ def main():
             out["valu"] = None
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, rays_per_frame)
+            # SURVEY.md section 8(d) / BASELINE.md section 2: the reference's own Python (numba.cuda kernels run as plain Python
+            # under an identity-decorator stand-in, the arithmetic NUMBA_ENABLE_CUDASIM=1 runs) cannot travel to the GPU box; its
+            # speed was measured once in the build container and is quoted as a constant with its provenance
+            out["cpu_baseline"]["reference_python"] = {
+                "value": 0.045, "unit": "Mrays/s", "cores": 1, "frame": "config 1: 128x128, 3 spheres + plane, depth 1",
+                "frame_s": 2.34, "rays_per_frame": 105404,
+                "provenance": "BASELINE.md section 2 / SURVEY.md section 8(d) [probe]: 2.34 s per config-1 frame on one core of the build "
+                              "container's 8-core Xeon @ 2.1 GHz (143 us per pixel); a constant, not measured in this run"}
         print(json.dumps(out), flush=True)
     pipe.close(r)
     r.close()

@@ -18,9 +18,11 @@
  *
  * Threading: a context is not thread-safe; use one context per host thread / per GPU.
  * Streams: rt_render_device may be called for one context on several streams (frames of a sequence in flight
- * together); the scheduler feedback inside the context is safe under that use.  rt_set_camera and rt_set_raygen
- * change host-side state only and apply to later launches; rt_set_scene and rt_set_pixel_loc rewrite device memory
- * that launches in flight still read: wait for those launches (rt_stream_sync / rt_sync) before calling them.
+ * together); the scheduler feedback inside the context is safe under that use.  rt_set_camera, rt_set_raygen and
+ * rt_set_scene apply to LATER launches only: camera and ray grid travel with every launch by value, and the scene
+ * lives in a ring of device buffers — a launch keeps reading the buffer that was current when it was queued, so frames
+ * in flight on any stream finish with the scene they were launched with.  rt_set_pixel_loc (the explicit grid of the
+ * literal drop-in) rewrites ONE device buffer: it waits for the whole device before it does.
  * The library has no CPU fallback: without a usable HIP device rt_create fails.
  */
 #ifndef MI355RT_H
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 #define RT_MAX_DEPTH 16      /* entries of rt_params.refl_pow (reflection bounces) */
 #define RT_MAX_SPHERES 1024  /* scene limits: the packed scene must fit one workgroup's LDS */
 #define RT_MAX_PLANES 64
@@ -124,6 +126,7 @@ typedef struct rt_kernel_info {
  *   re-traces shared taps, so its counts are lower than the reference algorithm's. */
 typedef struct rt_stats {
     uint64_t launches;            /* render launches */
+    uint64_t frames;              /* frames those launches rendered (rt_render_sequence: several per launch) */
     uint64_t launches_measuring;  /* ... that timed their tiles and rebuilt the dispatch order */
     uint64_t launches_settled;    /* ... that dispatched in a settled (kept) order */
     uint64_t table_builds;        /* cull-table sets built (one per new scene / camera position / depth bound) */
@@ -183,16 +186,17 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
  * (with pageable memory the runtime stages it).  Any host pointer is accepted by rt_render; these are an offer.
  * (The reference's `result.copy_to_host()` allocates its own pageable array, main.py:51.) */
 int rt_host_alloc(rt_ctx *ctx, size_t bytes, void **hptr);
-int rt_host_free(rt_ctx *ctx, void *hptr);
+int rt_host_free(rt_ctx *ctx, void *hptr);   /* ctx may be NULL: page-locked memory may outlive the context that allocated it */
 
 /* rt_render in two halves, for SEQUENCES of frames into host memory (an animation: main.py:41-51 in a loop).
  * rt_render_begin queues the launch and the copies of one frame on the stream of `slot` (0 <= slot < RT_RENDER_SLOTS)
  * and returns; rt_render_end(slot) returns when everything queued on that slot has arrived in the host buffers.  Frames
  * begun on different slots render and travel side by side — the copy of one frame overlaps the rendering of the next, so
  * with page-locked destinations (rt_host_alloc) a sequence runs at the slower of the two rates instead of their sum.
- * A second frame begun on a slot before its rt_render_end simply queues behind the first.  The camera, ray grid and scene
- * may be changed between two begins (each launch carries its own copy); the host buffers of a slot must stay untouched
- * until its rt_render_end.  Arguments and results as rt_render (same bytes). */
+ * A second frame begun on a slot before its rt_render_end simply queues behind the first.  The camera, the closed-form ray
+ * grid and the scene may be changed between two begins (camera and grid travel with the launch by value; the scene of a
+ * launch in flight stays in its own buffer of the context's ring, see "Streams" at the top); the host buffers of a slot
+ * must stay untouched until its rt_render_end.  Arguments and results as rt_render (same bytes). */
 #define RT_RENDER_SLOTS 4
 int rt_render_begin(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32, int slot);
 int rt_render_end(rt_ctx *ctx, int slot);
@@ -204,6 +208,21 @@ int rt_render_end(rt_ctx *ctx, int slot);
  * frame, plane_stride = w*h renders the slab in place.  Either pointer may be NULL. */
 int rt_render_device(rt_ctx *ctx, const rt_params *params, int x0, int x1, void *d_u8, void *d_f32,
                      int64_t plane_stride, void *stream);
+
+/* A SEQUENCE of n frames into device buffers with one call (the reference's driver launches frame after frame,
+ * main.py:41-47): frame i is stored at d_u8 + i * frame_stride bytes / d_f32 + i * frame_stride floats, each frame laid
+ * out as rt_render_device describes (frame_stride >= 3 * plane_stride; for RT_FLAG_U8_HWC >= 3 * row pitch * h).
+ *   cameras == NULL: n frames of the context's camera.  They are rendered by launches of `frames_per_launch` frames each
+ *     (0 = a default of 8; one launch renders its frames back to back in one grid, so one frame's last workgroups run
+ *     beside the next frame's first and the host pays one launch for all of them), launch g on streams[g % n_streams].
+ *   cameras != NULL: float64 (n, 12) — origin[3] then rotation[9] per frame (an animation).  One launch per frame, frame i
+ *     on streams[i % n_streams]; afterwards the context's camera is the last one.  The dispatch order measured under an
+ *     earlier camera is kept and refreshed every few frames (any order renders the same pixels).
+ * streams == NULL or n_streams == 0: everything on the context's stream.  Asynchronous like rt_render_device; the same
+ * pixels as n calls of it. */
+int rt_render_sequence(rt_ctx *ctx, const rt_params *params, int x0, int x1, int n, void *d_u8, void *d_f32,
+                       int64_t plane_stride, int64_t frame_stride, const double *cameras, void *const *streams,
+                       int n_streams, int frames_per_launch);
 
 /* Device memory owned by the caller (the DeviceNDArray that `cuda.to_device(np.zeros((3,w,h)))`
  * returns, main.py:32, and `result.copy_to_host()`, main.py:51).  The copies are ordered on the
@@ -241,9 +260,13 @@ int rt_get_kernel_info(rt_ctx *ctx, rt_kernel_info *info);
 int rt_get_stats(rt_ctx *ctx, rt_stats *stats);
 int rt_reset_stats(rt_ctx *ctx);
 
-/* Statistics: with a non-NULL device buffer of ceil((x1-x0)/8) * ceil(h/8) uint32, every later launch stores
- * the shader-clock cycles each 8x8 tile's wavefront took, tile index = tile_x * ceil(h/8) + tile_y
- * (what the reference's unused `timed` decorator, viewer/image.py:22-34, gestures at).  NULL turns it off. */
+/* Statistics: with a non-NULL device buffer of ceil((x1-x0)/8) * ceil(h/8) uint32, every later rt_render_device /
+ * rt_render_sequence launch stores the shader-clock cycles each 8x8 tile's wavefront took, tile index =
+ * tile_x * ceil(h/8) + tile_y with tile_x counted from the launch's x0 (what the reference's unused `timed` decorator,
+ * viewer/image.py:22-34, gestures at).  Defined for launches of the pixel frame into device buffers: the host-buffer
+ * entry points split large frames into column chunks (each chunk records from ITS first column into its own part of the
+ * buffer, so the frame's tiles still land at the indices above), and RT_AA_REFERENCE on the closed-form grid traces a
+ * half-pixel lattice instead of pixels and records nothing.  NULL turns it off. */
 int rt_set_tile_stats(rt_ctx *ctx, void *d_cycles);
 
 #ifdef __cplusplus

@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MI355RT_SO") or os.path.join(HERE, "libmi355rt.so")   # env override: A/B profiling of other builds
 
-RT_ABI_VERSION = 5
+RT_ABI_VERSION = 6
 RT_MAX_DEPTH = 16
 RT_MAX_SPHERES, RT_MAX_PLANES, RT_MAX_LIGHTS = 1024, 64, 64
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_STATE, RT_ERR_ALLOC = 0, -1, -2, -3, -4, -5
@@ -28,7 +28,7 @@ class rt_kernel_info(C.Structure):
 
 
 class rt_stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("launches", "launches_measuring", "launches_settled", "table_builds",
+    _fields_ = [(n, C.c_uint64) for n in ("launches", "frames", "launches_measuring", "launches_settled", "table_builds",
                                           "closest_queries", "hits", "shadow_traced", "shadow_skipped")] + \
                [("bounce_waves", C.c_uint64 * (RT_MAX_DEPTH + 1)), ("bounce_lanes", C.c_uint64 * (RT_MAX_DEPTH + 1))]
 
@@ -49,6 +49,8 @@ PROTOTYPES = {
     "rt_render_begin": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp, C.c_int]),
     "rt_render_end": (C.c_int, [_vp, C.c_int]),
     "rt_render_device": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
+    "rt_render_sequence": (C.c_int, [_vp, C.POINTER(rt_params), C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, C.c_int64, _dp,
+                                     C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "rt_sync": (C.c_int, [_vp]),
     "rt_stream_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "rt_stream_destroy": (C.c_int, [_vp, _vp]),

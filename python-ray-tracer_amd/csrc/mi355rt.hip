@@ -29,6 +29,7 @@ struct Buf {
 }  // namespace
 
 #define RT_FEEDBACK_SLOTS 8
+#define RT_SCENE_RING 4
 #define RT_COUNT_WORDS (4 + 2 * (RT_MAX_DEPTH + 1))   /* ray counters + per bounce {waves, alive lanes} */
 #define RT_RENDER_CHUNKS 8   /* upper bound; the pipeline uses ctx->render_chunks of them */
 
@@ -43,13 +44,23 @@ struct rt_ctx {
     int lanes_primary = 1, lanes_min_spheres = 161;   // MI355RT_LANES_MINS: the lane-owned traversal from that size on; MI355RT_LANES_PRIMARY=0: from bounce 1 on only
                                                       // (primary rays and their shadow rays wave-uniform: +2..3 % since the group level exists)
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
-    int order_group = 0;              // MI355RT_ORDER_GROUP: log2 of the blocks per dispatch group (0..6; 0 = every block on its own)
+    int order_group = -1;             // MI355RT_ORDER_GROUP: log2 of the blocks per XCD-affine dispatch group (0..6; 0 = every block on its
+                                      // own; default -1 = groups of 16 tiles)
+    int remeasure = 24;               // MI355RT_REMEASURE: launches a dispatch order measured under an older camera is kept for before
+                                      // the tile costs are measured again (a moving camera; any order renders the same frame)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
         hipStream_t stream = nullptr;
         Buf u8, f32;
     } slots[RT_RENDER_SLOTS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    Buf scene, pixel_loc, u8, f32;
+    // The packed scene records live in a ring of device buffers: rt_set_scene fills the NEXT one and launches carry the
+    // pointer of the one that was current when they were queued, so frames in flight on any stream keep the scene they
+    // were launched with (include/mi355rt.h: rt_render_begin).  A buffer comes up for reuse RT_SCENE_RING scene changes
+    // later; the streams that launched with it are synchronised then (by that time they have long finished with it).
+    Buf scene[RT_SCENE_RING];
+    std::vector<hipStream_t> scene_readers[RT_SCENE_RING];
+    int scene_cur = 0;
+    Buf pixel_loc, u8, f32;
     int S = 0, P = 0, L = 0;
     int NC = 0;                   // sphere clusters (0 = flat scene)
     double scene_extent2 = 0.0;   // max squared distance of lights / sphere surfaces from the world origin
@@ -60,12 +71,17 @@ struct rt_ctx {
     size_t lds_limit_set = 0;
     unsigned plane_codes = 0;         // axis codes of planes 0..3 (rt_device.h: KParams::plane_codes)
     unsigned *tile_stats = nullptr;   // caller-owned device buffer or NULL
-    // Scheduler feedback: a launch files its tile blocks by cost; a small kernel behind it (same stream) turns
-    // that into the dispatch order of the next launch.  (Running that kernel on a side stream, overlapped with
-    // the next render, was measured slower: the cross-stream event waits cost more than the 8 us they hide.)
+    // Scheduler feedback: a MEASURING launch stores its tile blocks' costs; a small kernel behind it (same stream) turns
+    // them into a dispatch order (rt::order_kernel).  The order lives in two buffers: launches dispatch in order[cur]
+    // while a measuring launch's order kernel writes order[cur ^ 1]; the context switches to the new one when a later
+    // launch (on any stream) finds the order kernel's event complete — so no stream ever waits for another stream's
+    // measuring launch (round 2: the other streams' first launch in a new order waited for it, and a measuring launch
+    // waited for everything the other streams had queued; with a camera that moves every frame that was a pipeline
+    // bubble per measurement).  The buffer a measurement overwrites was last read by launches queued before the previous
+    // switch; events recorded on their streams AT that switch (complete long before they are waited on) fence them.
     struct Feedback {
-        Buf hist, slot, order, group; // cost histograms, per-group (bucket, rank), dispatch order, per-group cost accumulators
-        struct Key {                  // launch geometry `order` was built for (valid = false: none)
+        Buf cost, gtmp, btmp, order[2]; // per-block costs of the measuring launch, order_kernel's scratch, the dispatch orders
+        struct Key {                  // launch geometry the orders were built for (valid = false: none)
             bool valid = false;
             int x0 = 0, x1 = 0, h = 0, aa = 0, depth = 0, spp = 0, wpw = 0;
             bool operator==(const Key &o) const
@@ -74,12 +90,16 @@ struct rt_ctx {
                        spp == o.spp && wpw == o.wpw;
             }
         } key;
-        hipStream_t stream = nullptr; // stream it was built on
-        unsigned long long epoch = 0; // ctx->epoch the costs were measured under
-        int builds = 0;               // consecutive builds under that key and epoch
+        int cur = 0;
+        bool have = false;            // order[cur] holds a complete order
+        bool building = false;        // a measuring launch and its order kernel are in flight, writing order[cur ^ 1]
+        unsigned long long epoch = 0; // ctx->epoch the costs behind order[cur] were measured under
+        unsigned long long build_epoch = 0;   // ... behind the order being built
+        int builds = 0;               // consecutive orders built under `epoch`
+        int since = 0;                // launches that used the order under a LATER epoch (moving camera) since the last measurement
         hipEvent_t done = nullptr;    // recorded behind every order kernel
-        hipEvent_t handover = nullptr; // recorded on the owner's stream when another stream takes the buffers over
-        std::vector<std::pair<hipStream_t, hipEvent_t>> readers;   // other streams dispatching in the settled order
+        std::vector<hipStream_t> users;                            // streams that launched in order[cur] since the last switch
+        std::vector<std::pair<hipStream_t, hipEvent_t>> fence;     // recorded at the last switch: what may still read order[cur ^ 1]
         std::vector<hipEvent_t> spare;
         unsigned long long stamp = 0; // last use (the least recently used geometry is replaced)
     } fbs[RT_FEEDBACK_SLOTS];         // one per launch geometry in use: slabs, chunks and AA modes do not evict each other
@@ -89,9 +109,12 @@ struct rt_ctx {
     std::vector<std::pair<hipStream_t, Buf>> lattice;   // per launching stream: float64 lattice samples (RT_AA_REFERENCE)
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
     unsigned long long scene_epoch = 1;   // bumped by rt_set_scene only
-    // The float32 cull tables (rt::tables_kernel) of the last few (scene, camera position, floor) combinations.
-    // A set is built on the stream of the first launch that needs it; other streams wait for that build once;
-    // before a set is overwritten, the building stream waits for whatever the streams that read it have queued.
+    // The float32 cull tables (rt::tables_kernel) of the last (scene, camera position, floor) combinations, PER STREAM: a
+    // set is built on the stream of the launch that needs it and read only by launches of that stream, so rebuilding a
+    // stream's older set is ordered behind its readers by the stream itself — no events, no cross-stream waits.  (Round 2
+    // shared three sets among the streams behind events; with a camera that moves every frame the events made every
+    // stream wait for the others' newest launches: frames of different streams no longer overlapped, +45 %.)  Frames
+    // of a static camera on n streams build n identical sets once (a few microseconds each).
     struct Tables {
         Buf buf;
         bool valid = false;
@@ -99,11 +122,10 @@ struct rt_ctx {
         double cam[3] = {0, 0, 0};
         float floor_anch = 0.0f;
         int anchors = -1;
-        hipEvent_t built = nullptr;
-        std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
-    } tables[3];
+    };
+    struct StreamTables { hipStream_t stream = nullptr; Tables sets[2]; };
+    std::vector<StreamTables> tables;
     unsigned long long table_stamp = 0;
-    std::vector<hipEvent_t> spare_events;
     std::string err;
 };
 
@@ -183,58 +205,35 @@ const void *kernel_variant(bool aa, bool park, int wpw, bool count = false)
               : (park ? (const void *)rt::render_kernel<false, true, 4> : (const void *)rt::render_kernel<false, false, 4>);
 }
 
-int get_event(rt_ctx *ctx, hipEvent_t *ev)
-{
-    if (!ctx->spare_events.empty()) { *ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); return RT_OK; }
-    RT_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    return RT_OK;
-}
-
-// The cull tables for this launch's scene / camera position / floor: reuse a built set or build one on `stream`.
+// The cull tables for this launch's scene / camera position / floor: reuse one of the stream's sets or rebuild its older one.
 int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const float **out)
 {
-    rt_ctx::Tables *hit = nullptr, *victim = nullptr;
-    for (auto &t : ctx->tables) {
-        if (t.valid && t.scene_epoch == ctx->scene_epoch && t.anchors == k.anchors && t.floor_anch == k.floor_anch &&
-            std::memcmp(t.cam, k.cam_o, sizeof t.cam) == 0) { hit = &t; break; }
-        if (!victim || (!t.valid && victim->valid) || (t.valid == victim->valid && t.stamp < victim->stamp)) victim = &t;
+    rt_ctx::StreamTables *st = nullptr;
+    for (auto &c : ctx->tables) if (c.stream == stream) { st = &c; break; }
+    if (!st) {
+        try { ctx->tables.emplace_back(); } catch (const std::bad_alloc &) { return fail(ctx, RT_ERR_ALLOC, "out of host memory"); }
+        st = &ctx->tables.back();
+        st->stream = stream;
     }
-    if (hit) {
-        bool known = false;
-        for (auto &r : hit->readers) known = known || r.first == stream;
-        if (!known) {                                          // first use on this stream: the build must be complete
-            hipEvent_t ev = nullptr;
-            int rc = get_event(ctx, &ev);
-            if (rc != RT_OK) return rc;
-            hit->readers.emplace_back(stream, ev);
-            RT_HIP(ctx, hipStreamWaitEvent(stream, hit->built, 0));
+    rt_ctx::Tables *victim = &st->sets[0];
+    for (auto &t : st->sets) {
+        if (t.valid && t.scene_epoch == ctx->scene_epoch && t.anchors == k.anchors && t.floor_anch == k.floor_anch &&
+            std::memcmp(t.cam, k.cam_o, sizeof t.cam) == 0) {
+            t.stamp = ++ctx->table_stamp;
+            *out = (const float *)t.buf.p;
+            return RT_OK;
         }
-        hit->stamp = ++ctx->table_stamp;
-        *out = (const float *)hit->buf.p;
-        return RT_OK;
+        if ((!t.valid && victim->valid) || (t.valid == victim->valid && t.stamp < victim->stamp)) victim = &t;
     }
     rt_ctx::Tables &t = *victim;
-    for (auto &r : t.readers) {                                // launches elsewhere may still read the set being replaced
-        if (r.first != stream) {
-            RT_HIP(ctx, hipEventRecord(r.second, r.first));
-            RT_HIP(ctx, hipStreamWaitEvent(stream, r.second, 0));
-        }
-        ctx->spare_events.push_back(r.second);
-    }
-    t.readers.clear();
     t.valid = false;
     const size_t bytes = rt::table_floats(k.S, k.NC, k.anchors) * sizeof(float);
+    if (t.buf.cap < (bytes ? bytes : 16)) RT_HIP(ctx, hipStreamSynchronize(stream));       // (growing frees the old buffer)
     int rc = ensure(ctx, t.buf, bytes ? bytes : 16);
     if (rc != RT_OK) return rc;
-    if (!t.built) RT_HIP(ctx, hipEventCreateWithFlags(&t.built, hipEventDisableTiming));
     hipLaunchKernelGGL(rt::tables_kernel, dim3(1), dim3(rt::TABLE_THREADS), 0, stream, k, (float *)t.buf.p);
     ctx->stats.table_builds++;
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipEventRecord(t.built, stream));
-    hipEvent_t ev = nullptr;
-    rc = get_event(ctx, &ev);
-    if (rc != RT_OK) return rc;
-    t.readers.emplace_back(stream, ev);
     t.scene_epoch = ctx->scene_epoch; t.anchors = k.anchors; t.floor_anch = k.floor_anch;
     std::memcpy(t.cam, k.cam_o, sizeof t.cam);
     t.valid = true;
@@ -243,7 +242,7 @@ int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const 
     return RT_OK;
 }
 
-int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream);
+int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream, int nframes, int64_t frame_stride);
 
 // The lattice buffer of a stream (RT_AA_REFERENCE with the closed-form grid renders the half-pixel lattice once into
 // float64 samples, then sums nine of them per pixel): one buffer per launching stream, so that frames in flight on
@@ -263,12 +262,19 @@ int lattice_buffer(rt_ctx *ctx, hipStream_t stream, size_t bytes, double **out)
     return rc;
 }
 
+// nframes > 1 (rt_render_sequence): that many frames of the current scene and camera, frame f into the outputs +
+// f * frame_stride elements — one launch for all of them where the dispatch order is settled.
 int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_f32, int64_t plane_stride,
-           hipStream_t stream)
+           hipStream_t stream, int nframes = 1, int64_t frame_stride = 0)
 {
     rt::KParams k;
     std::memset(&k, 0, sizeof k);
-    k.scene = (const double *)ctx->scene.p;
+    k.scene = (const double *)ctx->scene[ctx->scene_cur].p;
+    {
+        auto &rd = ctx->scene_readers[ctx->scene_cur];
+        if (std::find(rd.begin(), rd.end(), stream) == rd.end()) rd.push_back(stream);
+    }
+    k.nframes = 1;
     k.pixel_loc = ctx->explicit_grid ? (const double *)ctx->pixel_loc.p : nullptr;
     k.out_u8 = (uint8_t *)d_u8;
     k.out_f32 = (float *)d_f32;
@@ -315,24 +321,29 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
         int rc = lattice_buffer(ctx, stream, (size_t)(li1 - li0 + 1) * (size_t)LH * 3 * sizeof(double), &lat);
         if (rc != RT_OK) return rc;
         rt::KParams kl = k;
-        kl.aa = 0; kl.lattice = 1; kl.out_u8 = nullptr; kl.out_f32 = nullptr; kl.out_f64 = lat; kl.tile_cycles = nullptr;
+        kl.aa = 0; kl.lattice = 1; kl.out_u8 = nullptr; kl.out_f32 = nullptr; kl.out_f64 = lat; kl.tile_cycles = nullptr;   // (rt_set_tile_stats: pixel launches only)
         kl.w = (int)LW; kl.h = (int)LH; kl.x0 = li0; kl.x1 = li1 + 1; kl.plane_stride = 0;
         kl.tiles_y = ((int)LH + rt::TILE - 1) / rt::TILE;
         kl.ntiles = ((li1 + 1 - li0 + rt::TILE - 1) / rt::TILE) * kl.tiles_y;
-        rc = dispatch(ctx, p, kl, true, stream);
-        if (rc != RT_OK) return rc;
         k.out_f64 = lat; k.lat_x0 = li0; k.lat_h = (int)LH;
         const long long npx = (long long)(x1 - x0) * ctx->h;
-        hipLaunchKernelGGL(rt::aa_resolve_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, k);
-        RT_HIP(ctx, hipGetLastError());
+        for (int f = 0; f < nframes; ++f) {                    // the stream's one lattice buffer serves the frames in turn
+            rc = dispatch(ctx, p, kl, true, stream, 1, 0);
+            if (rc != RT_OK) return rc;
+            rt::KParams kf = k;
+            if (kf.out_u8) kf.out_u8 += (size_t)f * frame_stride;
+            if (kf.out_f32) kf.out_f32 += (size_t)f * frame_stride;
+            hipLaunchKernelGGL(rt::aa_resolve_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, kf);
+            RT_HIP(ctx, hipGetLastError());
+        }
         return RT_OK;
     }
-    return dispatch(ctx, p, k, false, stream);
+    return dispatch(ctx, p, k, false, stream, nframes, frame_stride);
 }
 
 // Chooses the kernel instantiation and the dispatch order for one launch of the render kernel over the tiles k
 // describes, and launches it.
-int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream)
+int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream, int nframes, int64_t frame_stride)
 {
     const int x0 = k.x0, x1 = k.x1;
     // Workgroup size: 2 tiles (wavefronts) for scenes whose LDS image (records + cull tables) is small, 4 otherwise
@@ -380,105 +391,109 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // Scheduler feedback (longest-first dispatch): a launch files its tile blocks by cost and dispatches in the
     // order built from the previous measured launch of the same range, depth and AA mode.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
-    const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
-    // XCD-affine block groups (rt::order_kernel): MI355RT_ORDER_GROUP = log2 blocks per group.  Off by default — groups of
-    // 8-32 blocks bring the write traffic of the headline frame from 41 to 32 MB (31.1 MB of pixels), but the coarser
-    // order costs more time than the traffic was costing (profiles/r02_order_group_sweep.txt: +0.3 % pipelined, +6..11 %
-    // on a single stream and on the larger scenes); the kernel is bound by instruction issue, not by HBM.
-    const int gshift = ctx->order_group > 0 ? ctx->order_group : 0;
+    const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 18);
+    // XCD-affine block groups (rt::order_kernel): runs of 2^gshift consecutive blocks (neighbours in y, which share 128-byte
+    // lines of the output planes) are rendered by ONE XCD, so that its L2 completes those lines before they leave for HBM;
+    // inside every XCD the order is block-level longest-first.  Default: groups of 16 tiles.  MI355RT_ORDER_GROUP overrides
+    // (0 = every block on its own: round 2's order, 1.39x the algorithmic write traffic on the headline frame).
+    const int gshift = ctx->order_group >= 0 ? ctx->order_group : (wpw == 2 ? 3 : 2);
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
     key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (lanes ? 32 : 0);
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
-    if (!fsel) {                                               // a free slot, else the least recently used geometry
+    if (!fsel && feedback) {                                   // a free slot, else the least recently used geometry
         for (auto &c : ctx->fbs) if (!fsel || (!c.key.valid && fsel->key.valid) || (c.key.valid == fsel->key.valid && c.stamp < fsel->stamp)) fsel = &c;
+        if (fsel->key.valid) RT_HIP(ctx, hipDeviceSynchronize());   // launches of the evicted geometry may still read its orders (rare: > 8 geometries)
+        for (auto &e : fsel->fence) fsel->spare.push_back(e.second);
+        fsel->fence.clear(); fsel->users.clear();
+        fsel->have = fsel->building = false; fsel->builds = 0; fsel->since = 0; fsel->cur = 0;
+        fsel->key = key;
     }
-    rt_ctx::Feedback &f = *fsel;
-    if (feedback && !f.done) {
-        RT_HIP(ctx, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
-        RT_HIP(ctx, hipEventCreateWithFlags(&f.handover, hipEventDisableTiming));
-    }
-    // Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile
-    // order, once from longest-first order): the costs are the same again, so the launch neither measures nor
-    // rebuilds -- it just dispatches in that order, on any stream (frames of a static scene can be pipelined
-    // over several streams).  Any rt_set_* call or another range/depth/AA mode starts measuring again.
-    const bool settled = feedback && f.key == key && f.epoch == ctx->epoch && f.builds >= 2
-                         && f.order.cap >= (size_t)grid * sizeof(unsigned);
-    // The feedback buffers belong to one stream at a time.  A launch on another stream measures only if the
-    // owner's last measuring launch has completed (it then takes the buffers over); otherwise it renders in
-    // plain order and leaves them alone.
-    bool measure = false;
-    if (settled) {
-        f.stamp = ++ctx->fb_stamp;
-        k.order = (const unsigned *)f.order.p;
-        if (stream != f.stream) {
-            bool known = false;
-            for (auto &r : f.readers) known = known || r.first == stream;
-            if (!known) {                                      // first settled launch of this stream: order complete?
+    static rt_ctx::Feedback none;                              // RT_FLAG_NO_FEEDBACK / one-block launches: no order, no measuring
+    rt_ctx::Feedback &f = (feedback && fsel) ? *fsel : none;
+    if (feedback) f.stamp = ++ctx->fb_stamp;
+    if (feedback && !f.done) RT_HIP(ctx, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    // the order being built is complete: switch to it.  Launches queued so far on the streams that used the old order may
+    // still read it; an event per such stream, recorded now, is what the measurement after next waits for before it
+    // overwrites that buffer.
+    if (feedback && f.building) {
+        const hipError_t q = hipEventQuery(f.done);
+        if (q == hipSuccess) {
+            f.cur ^= 1;
+            f.have = true;
+            f.building = false;
+            f.builds = (f.build_epoch == f.epoch) ? f.builds + 1 : 1;
+            f.epoch = f.build_epoch;
+            for (auto &e : f.fence) f.spare.push_back(e.second);
+            f.fence.clear();
+            for (hipStream_t us : f.users) {
                 hipEvent_t ev = nullptr;
                 if (!f.spare.empty()) { ev = f.spare.back(); f.spare.pop_back(); }
                 else RT_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                f.readers.emplace_back(stream, ev);
-                RT_HIP(ctx, hipStreamWaitEvent(stream, f.done, 0));
+                RT_HIP(ctx, hipEventRecord(ev, us));
+                f.fence.emplace_back(us, ev);
             }
+            f.users.clear();
+        } else (void)hipGetLastError();                        // hipErrorNotReady is an answer, not a failure
+    }
+    // An order built for this launch geometry is a valid permutation whatever has happened to scene and camera since: only
+    // how well it balances the end of the launch depends on them.
+    //  * Nothing that decides a tile's cost has changed since the order was rebuilt twice (once from plain tile order, once
+    //    from longest-first order): the costs are the same again, so launches neither measure nor rebuild — they dispatch
+    //    in that order, on any stream.
+    //  * Something has changed (rt_set_* bumped the epoch — a moving camera does so with every frame): launches still
+    //    dispatch in the order there is, and only every `remeasure`-th of them measures its tiles again (under that order)
+    //    and rebuilds.  Round 2 measured and rebuilt with every frame of a moving camera: +11 us per frame.
+    const bool same_epoch = f.epoch == ctx->epoch;
+    const bool settled = feedback && f.have && (same_epoch ? f.builds >= 2 : f.since < ctx->remeasure);
+    // A launch of several frames (rt_render_sequence) is ONE launch only in a settled order; until then its frames go
+    // through this function one by one (a measuring launch stores the costs of one frame).
+    if (nframes > 1 && (!settled || (long long)grid * nframes >= (1ll << 31))) {
+        for (int fr = 0; fr < nframes; ++fr) {
+            rt::KParams kf = k;
+            if (kf.out_u8) kf.out_u8 += (size_t)fr * frame_stride;
+            if (kf.out_f32) kf.out_f32 += (size_t)fr * frame_stride;
+            int rc = dispatch(ctx, p, kf, lattice, stream, 1, 0);
+            if (rc != RT_OK) return rc;
         }
-    } else if (feedback) {
-        measure = !f.key.valid || stream == f.stream || hipEventQuery(f.done) == hipSuccess;
-        (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
+        return RT_OK;
+    }
+    const bool measure = feedback && !settled && !f.building;  // one measurement in flight at a time (one cost buffer)
+    if (settled && !same_epoch) f.since++;
+    if (f.have) {
+        k.order = (const unsigned *)f.order[f.cur].p;
+        if (std::find(f.users.begin(), f.users.end(), stream) == f.users.end()) f.users.push_back(stream);
     }
     if (measure) {
-        f.stamp = ++ctx->fb_stamp;
-        // Taking the buffers over from another stream: hipEventQuery(f.done) only proves that the owner's last
-        // ORDER KERNEL has finished.  Settled launches the owner queued after it still read `order` (the owner is
-        // not in f.readers), so this stream waits for everything the owner has queued so far.
-        if (f.key.valid && f.stream != stream) {
-            RT_HIP(ctx, hipEventRecord(f.handover, f.stream));
-            RT_HIP(ctx, hipStreamWaitEvent(stream, f.handover, 0));
-        }
-        for (auto &r : f.readers) {                            // settled launches elsewhere may still read `order`
-            if (r.first != stream) {
-                RT_HIP(ctx, hipEventRecord(r.second, r.first));
-                RT_HIP(ctx, hipStreamWaitEvent(stream, r.second, 0));
-            }
-            f.spare.push_back(r.second);
-        }
-        f.readers.clear();
-        if (!f.hist.p) {
-            const size_t hbytes = (size_t)rt::ORDER_BUCKETS * sizeof(unsigned);
-            int rc0 = ensure(ctx, f.hist, hbytes);
-            if (rc0 != RT_OK) return rc0;
-            RT_HIP(ctx, hipMemsetAsync(f.hist.p, 0, hbytes, stream));
-        }
-        if (f.slot.cap < (size_t)grid * sizeof(unsigned) || f.order.cap < (size_t)grid * sizeof(unsigned)) f.key.valid = false;
-        int rc = ensure(ctx, f.slot, (size_t)grid * sizeof(unsigned));
-        if (rc == RT_OK) rc = ensure(ctx, f.order, (size_t)grid * sizeof(unsigned));
+        const size_t words = (size_t)grid * sizeof(unsigned);
+        int rc = ensure(ctx, f.cost, words);
+        if (rc == RT_OK) rc = ensure(ctx, f.btmp, words);
+        if (rc == RT_OK) rc = ensure(ctx, f.order[0], words);
+        if (rc == RT_OK) rc = ensure(ctx, f.order[1], words);
+        if (rc == RT_OK) rc = ensure(ctx, f.gtmp, words + sizeof(unsigned));
         if (rc != RT_OK) return rc;
-        const size_t gbytes = (((size_t)grid >> gshift) + 1) * sizeof(unsigned long long);
-        if (gshift && f.group.cap < gbytes) {                                // (the render kernel leaves every accumulator at zero again)
-            if (rc == RT_OK) rc = ensure(ctx, f.group, gbytes);
-            if (rc != RT_OK) return rc;
-            RT_HIP(ctx, hipMemsetAsync(f.group.p, 0, f.group.cap, stream));
+        for (auto &e : f.fence) {                              // (recorded at the last switch: complete long ago)
+            if (e.first != stream) RT_HIP(ctx, hipStreamWaitEvent(stream, e.second, 0));
+            f.spare.push_back(e.second);
         }
-        k.hist = (unsigned *)f.hist.p;
-        k.slot = (unsigned *)f.slot.p;
-        k.gstat = (unsigned long long *)f.group.p;
-        k.order_gshift = gshift;
-        k.order = (f.key == key) ? (const unsigned *)f.order.p : nullptr;
+        f.fence.clear();
+        k.cost = (unsigned *)f.cost.p;
     }
+    k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride;
     void *args[] = {(void *)&k};
-    RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(wgt), args, lds, stream));
+    RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid * (unsigned)nframes), dim3(wgt), args, lds, stream));
     ctx->stats.launches++;
+    ctx->stats.frames += (uint64_t)nframes;
     if (settled) ctx->stats.launches_settled++;
     if (measure) ctx->stats.launches_measuring++;
     if (measure) {
-        hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (unsigned *)f.hist.p,
-                           (const unsigned *)f.slot.p, (unsigned *)f.order.p, (int)grid, gshift);
+        hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (const unsigned *)f.cost.p,
+                           (unsigned *)f.gtmp.p, (unsigned *)f.btmp.p, (unsigned *)f.order[f.cur ^ 1].p, (int)grid, gshift);
         RT_HIP(ctx, hipEventRecord(f.done, stream));
-        f.builds = (f.key == key && f.epoch == ctx->epoch) ? f.builds + 1 : 1;
-        f.key = key;
-        f.stream = stream;
-        f.epoch = ctx->epoch;
+        f.building = true;
+        f.build_epoch = ctx->epoch;
+        f.since = 0;
     }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -517,6 +532,7 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_CLUSTER_MINS")) ctx->cluster_min = std::max(8, std::atoi(e));
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
+    if (const char *e = std::getenv("MI355RT_REMEASURE")) ctx->remeasure = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -534,22 +550,18 @@ int rt_destroy(rt_ctx *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (Buf *b : {&ctx->scene, &ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->counts})
+    for (Buf *b : {&ctx->pixel_loc, &ctx->u8, &ctx->f32, &ctx->counts})
         if (b->p) (void)hipFree(b->p);
+    for (Buf &b : ctx->scene) if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->lattice) if (e.second.p) (void)hipFree(e.second.p);
     for (auto &f : ctx->fbs) {
-        for (Buf *b : {&f.hist, &f.slot, &f.order, &f.group}) if (b->p) (void)hipFree(b->p);
-        for (auto &r : f.readers) (void)hipEventDestroy(r.second);
+        for (Buf *b : {&f.cost, &f.gtmp, &f.btmp, &f.order[0], &f.order[1]}) if (b->p) (void)hipFree(b->p);
+        for (auto &r : f.fence) (void)hipEventDestroy(r.second);
         for (hipEvent_t e : f.spare) (void)hipEventDestroy(e);
         if (f.done) (void)hipEventDestroy(f.done);
-        if (f.handover) (void)hipEventDestroy(f.handover);
     }
-    for (auto &t : ctx->tables) {
-        if (t.buf.p) (void)hipFree(t.buf.p);
-        if (t.built) (void)hipEventDestroy(t.built);
-        for (auto &r : t.readers) (void)hipEventDestroy(r.second);
-    }
-    for (hipEvent_t e : ctx->spare_events) (void)hipEventDestroy(e);
+    for (auto &st : ctx->tables)
+        for (auto &t : st.sets) if (t.buf.p) (void)hipFree(t.buf.p);
     for (hipStream_t st : {ctx->stream2, ctx->copy_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &sl : ctx->slots) {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
@@ -679,10 +691,16 @@ int rt_set_scene(rt_ctx *ctx, const float *spheres, int S, const float *lights, 
             bound(g * rt::SUPER * rt::CLUSTER, std::min(S, (g + 1) * rt::SUPER * rt::CLUSTER), sp);
         RT_HIP(ctx, hipSetDevice(ctx->device));
         const size_t bytes = rec.size() * sizeof(double);
-        int rc = ensure(ctx, ctx->scene, bytes);
+        // the next buffer of the ring: launches in flight keep reading the buffers they were queued with.  Whatever
+        // launched with THIS buffer did so RT_SCENE_RING scene changes ago; its streams are drained before it is rewritten.
+        const int next = (ctx->scene_cur + 1) % RT_SCENE_RING;
+        for (hipStream_t st : ctx->scene_readers[next]) RT_HIP(ctx, hipStreamSynchronize(st));
+        ctx->scene_readers[next].clear();
+        int rc = ensure(ctx, ctx->scene[next], bytes);
         if (rc != RT_OK) return rc;
-        RT_HIP(ctx, hipMemcpyAsync(ctx->scene.p, rec.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // rec is about to go out of scope
+        RT_HIP(ctx, hipMemcpyAsync(ctx->scene[next].p, rec.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // rec is about to go out of scope; other streams may launch at once
+        ctx->scene_cur = next;
         ctx->plane_codes = codes;
     } catch (const std::bad_alloc &) {
         return fail(ctx, RT_ERR_ALLOC, "out of host memory");
@@ -743,6 +761,8 @@ int rt_set_pixel_loc(rt_ctx *ctx, const double *pixel_loc, int w, int h)
     if (w < 1 || h < 1 || (long long)w * h > (1ll << 31)) return fail(ctx, RT_ERR_BAD_ARG, "frame size out of range");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)3 * w * h * sizeof(double);
+    // one buffer, read by every launch of an explicit grid on any stream: nothing may be in flight while it is rewritten
+    if (ctx->pixel_loc.p) RT_HIP(ctx, hipDeviceSynchronize());
     int rc = ensure(ctx, ctx->pixel_loc, bytes);
     if (rc != RT_OK) return rc;
     RT_HIP(ctx, hipMemcpyAsync(ctx->pixel_loc.p, pixel_loc, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -766,6 +786,52 @@ int rt_render_device(rt_ctx *ctx, const rt_params *params, int x0, int x1, void 
     } else if (plane_stride < (int64_t)(x1 - x0) * ctx->h) return fail(ctx, RT_ERR_BAD_ARG, "plane_stride smaller than the slab");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return launch(ctx, params, x0, x1, d_u8, d_f32, plane_stride, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int rt_render_sequence(rt_ctx *ctx, const rt_params *params, int x0, int x1, int n, void *d_u8, void *d_f32, int64_t plane_stride,
+                       int64_t frame_stride, const double *cameras, void *const *streams, int n_streams, int frames_per_launch)
+{
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (n < 0) return fail(ctx, RT_ERR_BAD_ARG, "rt_render_sequence: negative frame count");
+    if (n == 0) return RT_OK;
+    if (cameras) {                                            // check_params wants a camera: the first frame's
+        int rc0 = rt_set_camera(ctx, cameras, cameras + 3);
+        if (rc0 != RT_OK) return rc0;
+    }
+    int rc = check_params(ctx, params, x0, x1);
+    if (rc != RT_OK) return rc;
+    if (!d_u8 && !d_f32) return fail(ctx, RT_ERR_BAD_ARG, "both output pointers are NULL");
+    const bool hwc = (params->flags & RT_FLAG_U8_HWC) != 0;
+    if (hwc) {
+        if (d_f32) return fail(ctx, RT_ERR_BAD_ARG, "RT_FLAG_U8_HWC re-uses plane_stride as the image row pitch: render the float32 buffer in a separate call");
+        if (plane_stride < (int64_t)(x1 - x0)) return fail(ctx, RT_ERR_BAD_ARG, "row pitch smaller than the slab width");
+        if (n > 1 && frame_stride < 3 * plane_stride * ctx->h) return fail(ctx, RT_ERR_BAD_ARG, "frame_stride smaller than one image");
+    } else {
+        if (plane_stride < (int64_t)(x1 - x0) * ctx->h) return fail(ctx, RT_ERR_BAD_ARG, "plane_stride smaller than the slab");
+        if (n > 1 && frame_stride < 3 * plane_stride) return fail(ctx, RT_ERR_BAD_ARG, "frame_stride smaller than three planes");
+    }
+    if (n_streams < 0 || (n_streams > 0 && !streams)) return fail(ctx, RT_ERR_BAD_ARG, "rt_render_sequence: n_streams without a stream array");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    auto stream_of = [&](int i) { return (n_streams > 0 && streams[i % n_streams]) ? (hipStream_t)streams[i % n_streams] : ctx->stream; };
+    uint8_t *u8 = (uint8_t *)d_u8;
+    float *f32 = (float *)d_f32;
+    if (cameras) {                                            // an animation: one launch per frame, each with its own camera
+        for (int i = 0; i < n; ++i) {
+            rc = rt_set_camera(ctx, cameras + 12 * (size_t)i, cameras + 12 * (size_t)i + 3);
+            if (rc == RT_OK) rc = launch(ctx, params, x0, x1, u8 ? u8 + (size_t)i * frame_stride : nullptr,
+                                         f32 ? f32 + (size_t)i * frame_stride : nullptr, plane_stride, stream_of(i));
+            if (rc != RT_OK) return rc;
+        }
+        return RT_OK;
+    }
+    const int fpl = frames_per_launch > 0 ? frames_per_launch : 8;
+    for (int i = 0, g = 0; i < n; i += fpl, ++g) {
+        const int nf = std::min(fpl, n - i);
+        rc = launch(ctx, params, x0, x1, u8 ? u8 + (size_t)i * frame_stride : nullptr, f32 ? f32 + (size_t)i * frame_stride : nullptr,
+                    plane_stride, stream_of(g), nf, frame_stride);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
 }
 
 int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out_u8, float *out_f32)
@@ -825,11 +891,16 @@ int rt_render(rt_ctx *ctx, const rt_params *params, int x0, int x1, uint8_t *out
         const int num = (c == 0) ? 0 : (c == NCH ? 2 * (NCH - 1) : 2 * c - 1);          // of 2 (NCH - 1) half-units
         cx[c] = std::min(x1, x0 + (int)((long long)tiles * num / (2 * (NCH - 1))) * rt::TILE);
     }
+    unsigned *const tile_stats = ctx->tile_stats;
+    const int tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
     for (int c = 0; c < NCH; ++c) {
         hipStream_t s = instream ? ctx->chunk_stream[c] : ((c & 1) ? ctx->stream2 : ctx->stream);
         const size_t off = (size_t)(cx[c] - x0) * ctx->h, n = (size_t)(cx[c + 1] - cx[c]) * ctx->h;
+        // rt_set_tile_stats: a chunk records from its own first tile column on (chunk edges are multiples of the tile size)
+        if (tile_stats) ctx->tile_stats = tile_stats + (size_t)((cx[c] - x0) / rt::TILE) * tiles_y;
         rc = launch(ctx, params, cx[c], cx[c + 1], out_u8 ? (uint8_t *)ctx->u8.p + off : nullptr,
                     out_f32 ? (float *)ctx->f32.p + off : nullptr, (int64_t)npx, s);
+        ctx->tile_stats = tile_stats;
         if (rc != RT_OK) return rc;
         if (instream) {
             if (out_u8) RT_HIP(ctx, hipMemcpy2DAsync(out_u8 + off, npx, (uint8_t *)ctx->u8.p + off, npx, n, 3, hipMemcpyDeviceToHost, s));
@@ -900,9 +971,8 @@ int rt_host_alloc(rt_ctx *ctx, size_t bytes, void **hptr)
 
 int rt_host_free(rt_ctx *ctx, void *hptr)
 {
-    if (!ctx) return RT_ERR_BAD_ARG;
     if (!hptr) return RT_OK;
-    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx) RT_HIP(ctx, hipSetDevice(ctx->device));           // ctx == NULL: the memory outlived its context (allowed)
     RT_HIP(ctx, hipHostFree(hptr));
     return RT_OK;
 }
@@ -975,18 +1045,20 @@ static int forget_stream(rt_ctx *ctx, hipStream_t stream)
         if (ctx->lattice[i].first == stream) { if (ctx->lattice[i].second.p) (void)hipFree(ctx->lattice[i].second.p); ctx->lattice.erase(ctx->lattice.begin() + (long)i); }
         else ++i;
     }
-    for (auto &f : ctx->fbs) {
-        for (size_t i = 0; i < f.readers.size();) {
-            if (f.readers[i].first == stream) { f.spare.push_back(f.readers[i].second); f.readers.erase(f.readers.begin() + (long)i); }
+    for (auto &f : ctx->fbs) {                                  // (its work is complete: nothing of it reads an order any more)
+        for (size_t i = 0; i < f.fence.size();) {
+            if (f.fence[i].first == stream) { f.spare.push_back(f.fence[i].second); f.fence.erase(f.fence.begin() + (long)i); }
             else ++i;
         }
-        if (f.stream == stream) f.stream = ctx->stream;         // its work is complete: anyone may take over
+        f.users.erase(std::remove(f.users.begin(), f.users.end(), stream), f.users.end());
     }
-    for (auto &t : ctx->tables)
-        for (size_t i = 0; i < t.readers.size();) {
-            if (t.readers[i].first == stream) { ctx->spare_events.push_back(t.readers[i].second); t.readers.erase(t.readers.begin() + (long)i); }
-            else ++i;
-        }
+    for (auto &rd : ctx->scene_readers) rd.erase(std::remove(rd.begin(), rd.end(), stream), rd.end());
+    for (size_t i = 0; i < ctx->tables.size();) {               // the stream's own cull-table sets go with it
+        if (ctx->tables[i].stream == stream) {
+            for (auto &t : ctx->tables[i].sets) if (t.buf.p) (void)hipFree(t.buf.p);
+            ctx->tables.erase(ctx->tables.begin() + (long)i);
+        } else ++i;
+    }
     return RT_OK;
 }
 

@@ -82,11 +82,12 @@ struct KParams {
     uint8_t *out_u8;           // or nullptr
     float *out_f32;            // or nullptr
     unsigned *tile_cycles;     // or nullptr: per-tile wave cycles of this launch (rt_set_tile_stats)
-    unsigned *hist;            // or nullptr: scheduler feedback, 1024 cost buckets (zero on entry)
-    unsigned *slot;            // per block group: (bucket << 20) | arrival rank within the bucket
-    int order_gshift;          // log2 of the blocks per group of the dispatch order (order_kernel); 0 = every block on its own
-    unsigned long long *gstat; // per block group: (sum of block costs << 8) | blocks finished (zero on entry and on exit)
-    const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from the previous launch's costs
+    unsigned *cost;            // or nullptr: scheduler feedback — a measuring launch stores every tile block's cost (wave cycles / 4,
+                               // summed over the block's waves); order_kernel turns them into the next launches' dispatch order
+    const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs
+    int nframes, bpf;          // frames rendered by this launch (rt_render_sequence) and workgroups per frame: workgroup b renders
+                               // block order[b % bpf] of frame b / bpf into the outputs + (b / bpf) * frame_stride elements
+    long long frame_stride;
     const float *ftab;         // the float32 cull tables of this scene / camera / depth, built once by tables_kernel
     unsigned long long *ray_counts;   // counting instantiation only (RT_FLAG_COUNT_RAYS): {closest, shadow issued, shadow skipped, hits}
     double *out_f64;           // lattice instantiation: float64 (R,G,B) per lattice sample, [column - x0][row][3]; aa_resolve_kernel reads it
@@ -1124,25 +1125,28 @@ __device__ __forceinline__ uint8_t clip_color(double c)
 }
 
 // kernels.py:69-73: clip and store one pixel; off = (x - x0) h + y.
-__device__ __forceinline__ void store_pixel(const KParams &p, long long off, double R, double G, double B)
+// fo = element offset of this launch's frame (rt_render_sequence; 0 for a single frame)
+__device__ __forceinline__ void store_pixel(const KParams &p, long long off, long long fo, double R, double G, double B)
 {
     if (p.out_u8) {                                                           // common.py:60-63
         const uint8_t r8 = clip_color(R), g8 = clip_color(G), b8 = clip_color(B);
         const uint8_t c1 = p.u8_rgb ? g8 : b8, c2 = p.u8_rgb ? b8 : g8;
+        uint8_t *o8 = p.out_u8 + fo;
         if (p.u8_hwc) {                                                       // image layout: row y, column x, 3 bytes
             const long long xr = off / p.h, yy = off - xr * p.h;
-            uint8_t *px = p.out_u8 + (yy * p.plane_stride + xr) * 3;
+            uint8_t *px = o8 + (yy * p.plane_stride + xr) * 3;
             px[0] = r8; px[1] = c1; px[2] = c2;
         } else {
-            p.out_u8[off] = r8;
-            p.out_u8[p.plane_stride + off] = c1;
-            p.out_u8[2 * p.plane_stride + off] = c2;
+            o8[off] = r8;
+            o8[p.plane_stride + off] = c1;
+            o8[2 * p.plane_stride + off] = c2;
         }
     }
     if (p.out_f32) {
-        p.out_f32[off] = (float)R;
-        p.out_f32[p.plane_stride + off] = (float)G;
-        p.out_f32[2 * p.plane_stride + off] = (float)B;
+        float *o32 = p.out_f32 + fo;
+        o32[off] = (float)R;
+        o32[p.plane_stride + off] = (float)G;
+        o32[2 * p.plane_stride + off] = (float)B;
     }
 }
 
@@ -1334,10 +1338,14 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
     // permutation of the tile blocks sorted by the cycles they took in the previous launch (order_kernel).
     // Any permutation renders every tile exactly once; only the length of the launch's tail depends on it.
-    const int block = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;
+    // A launch may carry several frames of the same scene and camera (rt_render_sequence): workgroups [f bpf, (f+1) bpf)
+    // render frame f, each frame in the same order, so one frame's last workgroups run beside the next frame's first.
+    int bid = (int)blockIdx.x;
+    if (p.nframes > 1) bid -= (bid / p.bpf) * p.bpf;
+    const int block = p.order ? (int)p.order[bid] : bid;
     const int tile = block * WAVES_PER_WG + wave;
     if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
-    const unsigned long long t_begin = (p.tile_cycles || p.hist) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
     const int x = p.x0 + tx * TILE + (lane >> 3);
     const int y = ty * TILE + (lane & 7);
@@ -1399,7 +1407,11 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
         if constexpr (LAT) {                                                  // one float64 (R,G,B) per lattice sample
             double *q = p.out_f64 + off * 3;
             q[0] = R; q[1] = G; q[2] = B;
-        } else store_pixel(p, off, R, G, B);
+        } else {
+            // the frame index is formed again here (a wave-uniform division) instead of being carried through the trace
+            const long long fo = opaque(p.nframes) > 1 ? (long long)((int)blockIdx.x / p.bpf) * p.frame_stride : 0ll;
+            store_pixel(p, off, fo, R, G, B);
+        }
     }
     if constexpr (COUNT) {                                                    // rt_get_stats: one atomic per wave and counter
         unsigned v[4] = {cnt.n_closest, cnt.n_issued, cnt.n_skipped, cnt.n_hit};
@@ -1410,38 +1422,14 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
             if ((threadIdx.x & 63) == 0 && p.ray_counts) atomicAdd(&p.ray_counts[c], (unsigned long long)v[c]);
         }
     }
-    if ((p.tile_cycles || p.hist) && (threadIdx.x & 63) == 0) {               // timing only; never feeds a pixel
+    if ((p.tile_cycles || p.cost) && (threadIdx.x & 63) == 0) {               // timing only; never feeds a pixel
         const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
         if (p.tile_cycles) p.tile_cycles[block * WAVES_PER_WG + (threadIdx.x >> 6)] = cyc;
-        if (p.hist) {
-            // the workgroup's cost = sum over its waves; the wave that finishes last adds it to the block GROUP's cost
-            // (order_kernel: a run of consecutive tiles that is dispatched together), and the block that completes the
-            // group files it under the bucket of its mean block cost, taking as many ranks as it has blocks
+        if (p.cost) {
+            // the block's cost = sum over its waves; the wave that finishes last stores it
             const int expected = (p.ntiles - block * WAVES_PER_WG < WAVES_PER_WG) ? p.ntiles - block * WAVES_PER_WG : WAVES_PER_WG;
             atomicAdd(&wgstat[0], cyc >> 2);
-            if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) {
-                const unsigned mine = atomicAdd(&wgstat[0], 0u);
-                if (p.order_gshift == 0) {                                     // every block on its own
-                    const int bkt = order_bucket(mine);
-                    p.slot[block] = ((unsigned)bkt << 20) | atomicAdd(&p.hist[bkt], 1u);
-                } else {
-                    const int GB = 1 << p.order_gshift;                        // blocks per group
-                    const int nblocks = (p.ntiles + WAVES_PER_WG - 1) / WAVES_PER_WG;
-                    const int g = block >> p.order_gshift;
-                    const int in_group = (nblocks - g * GB < GB) ? nblocks - g * GB : GB;
-                    // one 64-bit atomic carries the group's cost sum and its count of finished blocks; the block that
-                    // completes the group files it under its mean block cost
-                    const unsigned long long old = atomicAdd(&p.gstat[g], ((unsigned long long)mine << 8) | 1ull);
-                    if ((int)(old & 255ull) == in_group - 1) {
-                        if (in_group == GB) {                                  // (the one short group at the end goes last anyway)
-                            const unsigned long long mean = ((old >> 8) + mine) >> p.order_gshift;
-                            const int bkt = order_bucket(mean > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)mean);
-                            p.slot[g] = ((unsigned)bkt << 20) | atomicAdd(&p.hist[bkt], 1u);
-                        }
-                        p.gstat[g] = 0ull;
-                    }
-                }
-            }
+            if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
         }
     }
 }
@@ -1467,60 +1455,89 @@ __global__ __launch_bounds__(256) void aa_resolve_kernel(const KParams p)
         }
         R = R / 9; G = G / 9; B = B / 9;                                      // :63-65
     }
-    store_pixel(p, idx, R, G, B);
+    store_pixel(p, idx, 0ll, R, G, B);
 }
 
-// Builds the next launch's dispatch order from what this launch recorded: longest-first, and XCD-affine.
+// Builds the dispatch order of the following launches from the block costs a measuring launch stored: longest-first WITHIN
+// every XCD, and XCD-affine.
 //
-// The dispatcher hands workgroup i to XCD i mod 8, and every XCD has its own L2.  A workgroup writes 16-pixel runs of
-// the output planes (16 B of a uint8 plane, 64 B of a float32 plane); the rest of each 128-byte line belongs to its
-// neighbours in y.  When those run on other XCDs, or on the same one much later, every fragment of the line is written
-// back on its own (WRITE_SIZE 41 MB per 1080p frame for 31 MB of pixels); written by one XCD within a short time, the
-// line is completed in that L2 and leaves it once.  So the unit of the order is a GROUP of blocks — a run of
-// ORDER_GROUP_TILES consecutive tiles (y runs fastest) — that goes to one XCD as a whole.  The groups are sorted by
-// decreasing mean block cost (a counting sort on a 1024-bucket logarithmic key, 5 mantissa bits per octave, whose
-// histogram and within-bucket ranks the render kernel has already produced: what is left is a prefix sum over the
-// buckets and one scatter) and dealt to the XCDs in turn: the group of sorted rank r belongs to XCD r mod 8, so every
-// XCD works down every eighth group of the list, and its block i sits at position 8 ((r / 8) gb + i) + r mod 8.
-// The last (fewer than 8) groups of the list share the positions behind those rows evenly, and the short group at the
-// end of the frame, if there is one, comes last.  The output is a permutation of [0, nblocks) by construction.
-// Also re-zeroes the histogram for the next launch.
-__global__ __launch_bounds__(ORDER_THREADS) void order_kernel(unsigned *__restrict__ hist, const unsigned *__restrict__ slot,
-                                                               unsigned *__restrict__ order, int nblocks, int gshift)
+// The dispatcher hands workgroup i to XCD i mod 8, and every XCD has its own L2.  A two-wave workgroup writes 16-pixel runs
+// of the output planes (16 B of a uint8 plane, 64 B of a float32 plane); the rest of each 128-byte line belongs to its
+// neighbours in y.  When those run on other XCDs every fragment of the line is written back on its own (round 2: WRITE_SIZE
+// 41 MB per 1080p frame for 31 MB of pixels); written by one XCD, the line is completed in that L2 and leaves it once.
+// So WHICH XCD renders a block is decided for GROUPS of 2^gshift consecutive blocks (y runs fastest: neighbours in y), and
+// WHEN it renders it block by block:
+//   1. the groups are sorted by decreasing mean block cost (counting sort, 1024 logarithmic buckets) and dealt to the XCDs
+//      in serpentine order — rank r goes to XCD r mod 8 in even rows of eight and 7 - r mod 8 in odd ones — so every XCD
+//      gets the same number of groups and nearly the same total cost;
+//   2. every XCD's blocks are sorted by decreasing cost of their own (a second counting sort, per XCD), and the XCD's j-th
+//      block takes position 8 j + xcd of the order.  Round 2's XCD-affine order sorted whole groups (a coarser order: +6..14 %
+//      on one stream); here the order inside an XCD is as fine as the plain longest-first order.
+// The groups that do not fill a row of eight and the short group at the end of the frame share the positions behind those
+// rows, longest first.  The output is a permutation of [0, nblocks) by construction; any permutation renders the same frame.
+// gtmp: nblocks / 2^gshift + 1 words, btmp: nblocks words of scratch.
+__global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__restrict__ cost, unsigned *__restrict__ gtmp,
+                                                               unsigned *__restrict__ btmp, unsigned *__restrict__ order, int nblocks, int gshift)
 {
-    __shared__ unsigned start[ORDER_BUCKETS];
+    __shared__ unsigned hist[(ORDER_XCDS + 1) * ORDER_BUCKETS];     // [class][bucket]; class ORDER_XCDS = the leftover blocks
     __shared__ unsigned scan[ORDER_THREADS / 64];
-    const int i = threadIdx.x;                          // ORDER_THREADS == ORDER_BUCKETS; thread i owns bucket 1023-i
-    const unsigned v = hist[ORDER_BUCKETS - 1 - i];
-    hist[ORDER_BUCKETS - 1 - i] = 0u;
-    // inclusive scan in descending key order: shuffles inside each of the 16 waves, then the wave totals
-    unsigned incl = v;
-    const int lane = i & 63, wv = i >> 6;
+    static_assert(ORDER_THREADS == ORDER_BUCKETS, "thread i owns bucket 1023 - i");
+    const int i = threadIdx.x, lane = i & 63, wv = i >> 6;
+    const int gb = 1 << gshift;
+    const int full = nblocks >> gshift;                 // groups of gb blocks; a shorter one may follow
+    const int rows = full / ORDER_XCDS;                 // rows of eight groups: one group per XCD each
+    // in place: hist[c][b] (counts per bucket) -> exclusive offsets in descending bucket order, for classes [0, nc)
+    auto scan_classes = [&](int nc) {
+        for (int c = 0; c < nc; ++c) {
+            __syncthreads();
+            const unsigned v = hist[c * ORDER_BUCKETS + ORDER_BUCKETS - 1 - i];
+            unsigned incl = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-    }
-    if (lane == 63) scan[wv] = incl;                    // wave totals
-    __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wv; ++w) base += scan[w];
-    start[ORDER_BUCKETS - 1 - i] = base + incl - v;     // exclusive offset (in groups) of bucket 1023-i
-    __syncthreads();
-    const int gb = 1 << gshift;                         // blocks per group
-    const int full = nblocks / gb;                      // groups of gb blocks (sorted); a shorter one may follow
-    const int rows = full / ORDER_XCDS, rest = full - rows * ORDER_XCDS;
-    for (int b = i; b < nblocks; b += ORDER_THREADS) {
-        const int g = b / gb, k = b - g * gb;
-        unsigned pos = (unsigned)b;                     // the short group at the end keeps its place
-        if (g < full) {
-            const unsigned s = slot[g];
-            const int r = (int)(start[s >> 20] + (s & 0xFFFFFu));
-            const int q = r / ORDER_XCDS, c = r - q * ORDER_XCDS;
-            pos = (q < rows) ? (unsigned)(ORDER_XCDS * (q * gb + k) + c)
-                             : (unsigned)(ORDER_XCDS * rows * gb + rest * k + c);
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (lane == 63) scan[wv] = incl;            // wave totals
+            __syncthreads();
+            unsigned base = 0;
+            for (int w = 0; w < wv; ++w) base += scan[w];
+            hist[c * ORDER_BUCKETS + ORDER_BUCKETS - 1 - i] = base + incl - v;
         }
-        order[pos] = (unsigned)b;
+        __syncthreads();
+    };
+    for (int k = i; k < (ORDER_XCDS + 1) * ORDER_BUCKETS; k += ORDER_THREADS) hist[k] = 0u;
+    __syncthreads();
+    // 1. groups by mean block cost
+    for (int g = i; g < full; g += ORDER_THREADS) {
+        unsigned long long sum = 0;
+        for (int k = 0; k < gb; ++k) sum += cost[(g << gshift) + k];
+        const unsigned mean = (unsigned)(sum >> gshift);
+        const int bkt = order_bucket(mean);
+        gtmp[g] = ((unsigned)bkt << 20) | atomicAdd(&hist[bkt], 1u);
+    }
+    scan_classes(1);
+    for (int g = i; g < full; g += ORDER_THREADS) {
+        const unsigned s = gtmp[g];
+        const int r = (int)(hist[s >> 20] + (s & 0xFFFFFu));                 // rank among the groups, most expensive first
+        const int q = r / ORDER_XCDS, c = r - q * ORDER_XCDS;
+        gtmp[g] = q < rows ? (unsigned)((q & 1) ? ORDER_XCDS - 1 - c : c) : (unsigned)ORDER_XCDS;
+    }
+    __syncthreads();
+    for (int k = i; k < (ORDER_XCDS + 1) * ORDER_BUCKETS; k += ORDER_THREADS) hist[k] = 0u;
+    __syncthreads();
+    // 2. blocks by their own cost, per XCD
+    for (int b = i; b < nblocks; b += ORDER_THREADS) {
+        const int g = b >> gshift;
+        const unsigned x = g < full ? gtmp[g] : (unsigned)ORDER_XCDS;
+        const int bkt = order_bucket(cost[b]);
+        btmp[b] = (x << 28) | ((unsigned)bkt << 18) | atomicAdd(&hist[x * ORDER_BUCKETS + bkt], 1u);     // nblocks < 2^18 (host)
+    }
+    scan_classes(ORDER_XCDS + 1);
+    const unsigned tail = (unsigned)(ORDER_XCDS * rows * gb);                // first position behind the rows
+    for (int b = i; b < nblocks; b += ORDER_THREADS) {
+        const unsigned s = btmp[b], x = s >> 28;
+        const unsigned j = hist[x * ORDER_BUCKETS + ((s >> 18) & 1023u)] + (s & 0x3FFFFu);
+        order[x < (unsigned)ORDER_XCDS ? ORDER_XCDS * j + x : tail + j] = (unsigned)b;
     }
 }
 

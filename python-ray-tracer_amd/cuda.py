@@ -46,15 +46,30 @@ class DeviceNDArray:
     nbytes = property(lambda self: self._host.nbytes)
 
     def _device_buffer(self, renderer):
+        # a buffer of a context that has been closed since (cuda.close(), or another Renderer is current now) is gone
+        # with that context: never hand its address to a new one
+        if self._dptr is not None and (self._renderer is not renderer or getattr(self._renderer, "closed", False)):
+            if self._dirty and not getattr(self._renderer, "closed", False):
+                self._host = self.copy_to_host()
+            # (dirty under a CLOSED context: what the launch wrote went with that context; the array restarts from the
+            # host values it last held — copy_to_host() before the next launch would have raised)
+            self._free()
         if self._dptr is None:
             self._renderer = renderer
             self._dptr = renderer.malloc(self._host.nbytes)
         return self._dptr
 
+    def _free(self):
+        if self._dptr is not None and not getattr(self._renderer, "closed", False):
+            self._renderer.free(self._dptr)
+        self._dptr, self._renderer, self._dirty = None, None, False
+
     def copy_to_host(self):
         """A new host array with the current contents (numba's semantics).  Once a launch has written the device
         buffer, that buffer is the truth: one device-to-host copy straight into the array that is returned."""
         if self._dirty:
+            if getattr(self._renderer, "closed", False):
+                raise RuntimeError("DeviceNDArray: its context was closed before the contents were copied back")
             out = np.empty(self._host.shape, self._host.dtype)
             self._renderer.sync()
             self._renderer.d2h(out, self._dptr)
@@ -67,8 +82,7 @@ class DeviceNDArray:
 
     def __del__(self):
         try:
-            if self._dptr is not None:
-                self._renderer.free(self._dptr)
+            self._free()
         except Exception:
             pass
 

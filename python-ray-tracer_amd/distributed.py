@@ -169,14 +169,14 @@ class SequencePipeline:
     submit(launch) queues one frame: launch(u8, f32, stream) must enqueue the rendering of this rank's slab into
     columns [0, ws) of the (3, ws_pad, h) tensors `u8` / `f32` (plane stride = self.plane_stride elements; ws_pad = ws
     unless the ranks' slabs are unequal) on `stream` (a raw stream handle, or None on CPU, where it runs synchronously).
-    drain() completes everything queued.  on_frames(first_index, frames, count), if given, is called on `dst` (with
+    drain() completes everything queued.  on_frames(first_index, frames, count[, frames_f32 with gather_f32]), if given, is called on `dst` (with
     rotate_root: on the batch's own root) for every assembled batch (`frames` is (F, 3, w, h); only the first `count` are new).  Without a process group
     (dist=None) nothing is exchanged and on_frames is not called; last_slab() returns the newest slab.
 
     On a CUDA/HIP device this uses torch streams and events; on CPU (the gloo tests) everything is synchronous."""
 
     def __init__(self, w, h, ws, device, dist=None, dst=0, streams=3, frames_per_gather=8, want_f32=True, on_frames=None,
-                 bounds=None, rotate_root=False):
+                 bounds=None, rotate_root=False, frames_per_launch=1, gather_f32=False):
         import torch
         self.torch, self.dist, self.dst, self.on_frames = torch, dist, dst, on_frames
         # rotate_root: batch b is assembled on rank (dst + b) % world instead of always on `dst`, and on_frames is called
@@ -186,12 +186,17 @@ class SequencePipeline:
         self.batches = 0                        # batches closed so far (all ranks count alike)
         self.gpu = torch.device(device).type == "cuda"
         self.NS = max(1, int(streams)) if self.gpu else 1
-        self.F = max(1, int(frames_per_gather)) if dist is not None else 1
+        # F = frames per batch: the frames one gather moves (with a process group) / one launch of submit_frames() renders
+        self.F = max(1, int(frames_per_gather)) if dist is not None else max(1, int(frames_per_launch))
         self.SLOTS = 2 if dist is not None else self.NS
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.NS)] if self.gpu else [None]
         self.comm = torch.cuda.Stream(device=device) if (self.gpu and dist is not None) else None
         self.gatherer = FrameGatherer(w, h, torch.uint8, device, dist, dst=dst, slots=self.SLOTS, batch=self.F, bounds=bounds,
                                       any_root=self.rotate_root) if dist is not None else None
+        # gather_f32: the float32 pre-clip planes (the artefact north_star's 1e-5 tolerance is stated on) are assembled too,
+        # by a second padded gather per batch (4x the bytes of the uint8 one; off by default — bench.py --gather f32)
+        self.gatherer32 = FrameGatherer(w, h, torch.float32, device, dist, dst=dst, slots=self.SLOTS, batch=self.F, bounds=bounds,
+                                        any_root=self.rotate_root) if (dist is not None and gather_f32 and want_f32) else None
         if self.gatherer is not None:
             assert self.gatherer.ws == ws, "ws must be this rank's slab width under `bounds`"
         # slabs are stored padded to the widest rank's width (one gather even when the slabs are unequal): render
@@ -217,8 +222,13 @@ class SequencePipeline:
         ctx = self.torch.cuda.stream(self.comm) if self.comm is not None else _nullcontext()
         with ctx:                               # the gather's stream dependencies follow torch's current stream
             f = self.gatherer.finish(slot)
+            f32 = self.gatherer32.finish(slot) if self.gatherer32 is not None else None
             if f is not None and self.on_frames is not None:
-                self.on_frames(self.first[slot], f if self.F > 1 else f.unsqueeze(0), self.count[slot])
+                if self.gatherer32 is not None:
+                    self.on_frames(self.first[slot], f if self.F > 1 else f.unsqueeze(0), self.count[slot],
+                                   f32 if self.F > 1 else f32.unsqueeze(0))
+                else:
+                    self.on_frames(self.first[slot], f if self.F > 1 else f.unsqueeze(0), self.count[slot])
         self.first[slot] = None
 
     def _close_batch(self, slot):
@@ -230,6 +240,17 @@ class SequencePipeline:
         self.batches += 1
         with ctx:
             self.gatherer.submit(self.u8[slot], slot, dst=root)
+            if self.gatherer32 is not None:
+                self.gatherer32.submit(self.f32[slot], slot, dst=root)
+
+    def _open_batch(self, slot, idx):
+        if self.first[slot] is not None:        # the slot's slabs are reused: its exchange must have completed
+            self._collect(slot)
+            if self.comm is not None:
+                ev = self.comm.record_event()
+                for t in self.streams:
+                    t.wait_event(ev)
+        self.first[slot], self.count[slot] = idx, 0
 
     def submit(self, launch):
         i = self.n
@@ -237,25 +258,49 @@ class SequencePipeline:
         idx = self.index
         self.index += 1
         handle = self.handles[i % self.NS]
-        if self.gatherer is None:
-            b = i % self.SLOTS
-            self._last = self.u8v[b][0]
-            launch(self._last, self.f32v[b][0] if self.f32v is not None else None, handle)
-            return
         slot, j = (i // self.F) % self.SLOTS, i % self.F
+        if self.gatherer is None:
+            self._last = self.u8v[slot][j]
+            launch(self._last, self.f32v[slot][j] if self.f32v is not None else None, handle)
+            return
         if j == 0:
-            if self.first[slot] is not None:    # the slot's slabs are reused: its exchange must have completed
-                self._collect(slot)
-                if self.comm is not None:
-                    ev = self.comm.record_event()
-                    for t in self.streams:
-                        t.wait_event(ev)
-            self.first[slot], self.count[slot] = idx, 0
+            self._open_batch(slot, idx)
         self._last = self.u8v[slot][j]
         launch(self._last, self.f32v[slot][j] if self.f32v is not None else None, handle)
         self.count[slot] += 1
         if j == self.F - 1:                     # the batch is complete: one gather
             self._close_batch(slot)
+
+    def submit_frames(self, launch_seq, count):
+        """Queue `count` frames, a whole batch (F frames) per call of launch_seq(u8, f32, nframes, stream): `u8` / `f32` are
+        (nframes, 3, ws_pad, h) tensors (consecutive frames of one batch buffer: frame stride = 3 * plane_stride) and the
+        callback renders all of them on `stream` — with Renderer.render_sequence that is ONE kernel launch per batch, so a
+        settled frame costs the host a fraction of a launch (every frame a Python call and a launch of its own: ~10 us, more
+        than a 1/8 slab of the headline frame takes to render).  Batches go round-robin over the streams.  Returns the
+        (stream index, frames) of every launch made, in order."""
+        made = []
+        while count > 0:
+            i = self.n
+            b = i // self.F
+            slot, j = b % self.SLOTS, i % self.F
+            nf = min(count, self.F - j)
+            si = b % self.NS
+            if self.gatherer is not None and j == 0:
+                self._open_batch(slot, self.index)
+            whole = (j == 0 and nf == self.F)
+            u8 = self.u8[slot] if whole else self.u8[slot][j:j + nf]
+            f32 = None if self.f32 is None else (self.f32[slot] if whole else self.f32[slot][j:j + nf])
+            launch_seq(u8, f32, nf, self.handles[si])
+            self._last = self.u8v[slot][j + nf - 1]
+            self.n += nf
+            self.index += nf
+            count -= nf
+            made.append((si, nf))
+            if self.gatherer is not None:
+                self.count[slot] += nf
+                if j + nf == self.F:
+                    self._close_batch(slot)
+        return made
 
     def drain(self):
         """Complete every queued frame (a partly filled last batch is exchanged as it is)."""

@@ -2,6 +2,7 @@
 = one GPU.  All pixel work happens in libmi355rt.so; this class only marshals arrays."""
 import ctypes as C
 import itertools
+import weakref
 
 import numpy as np
 
@@ -35,6 +36,26 @@ def _f32(a, rows, name):
 _serials = itertools.count(1)
 
 
+class _PinnedBlock:
+    """One page-locked allocation of rt_host_alloc.  It lives as long as any numpy view of it does (the view's buffer
+    object holds it) and is freed when the last one goes — not when the Renderer that made it closes, whose close() would
+    otherwise leave those views pointing at freed memory.  release() frees it at once (no view may be used afterwards)."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def release(self):
+        if self.ptr:
+            ptr, self.ptr = self.ptr, 0
+            self.lib.rt_host_free(None, C.c_void_p(ptr))     # ctx = NULL: no context needed to free page-locked memory
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class Renderer:
     def __init__(self, device=0, lib=None):
         self.serial = next(_serials)     # process-unique (id() values are reused after garbage collection)
@@ -45,7 +66,8 @@ class Renderer:
             raise RenderError(st, self._lib.rt_last_error(None).decode())
         self.device = int(device)
         self.w = self.h = None
-        self._pinned = {}                # host_array(): data address -> allocation
+        self._pinned = weakref.WeakValueDictionary()     # host_array(): data address -> _PinnedBlock (owned by the arrays)
+        self.closed = False
         self.generation = {"scene": 0, "camera": 0, "grid": 0}   # bumped by every set_*: caches above this class key on it
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -54,12 +76,11 @@ class Renderer:
             raise RenderError(st, self._lib.rt_last_error(self._ctx).decode())
 
     def close(self):
+        # (page-locked arrays handed out by host_array() stay valid: each is freed with its last numpy view)
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            for ptr in list(getattr(self, "_pinned", {}).values()):
-                self._lib.rt_host_free(self._ctx, C.c_void_p(ptr))
-            self._pinned = {}
             self._lib.rt_destroy(self._ctx)
             self._ctx = C.c_void_p()
+        self.closed = True
 
     def __del__(self):
         try:
@@ -172,14 +193,17 @@ class Renderer:
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
         self._check(self._lib.rt_host_alloc(self._ctx, n, C.byref(ptr)))
-        arr = np.frombuffer((C.c_uint8 * n).from_address(ptr.value), dtype=dtype).reshape(shape)
-        self._pinned[arr.ctypes.data] = ptr.value
+        buf = (C.c_uint8 * n).from_address(ptr.value)
+        buf._owner = block = _PinnedBlock(self._lib, ptr.value)     # every view of `buf` keeps the allocation alive
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned[arr.ctypes.data] = block
         return arr
 
     def release_host_array(self, arr):
-        ptr = self._pinned.pop(arr.ctypes.data, None)
-        if ptr and self._ctx.value:
-            self._check(self._lib.rt_host_free(self._ctx, C.c_void_p(ptr)))
+        """Free the allocation behind `arr` now; neither `arr` nor any other view of it may be used afterwards."""
+        block = self._pinned.pop(arr.ctypes.data, None)
+        if block is not None:
+            block.release()
 
     def host_arrays(self, want_f32=False, pinned=True):
         """(uint8, float32 or None) output arrays for a full frame, page-locked or plain."""
@@ -199,6 +223,32 @@ class Renderer:
         self._check(self._lib.rt_render_device(self._ctx, C.byref(params), int(x0), int(x1),
                                                C.c_void_p(d_u8) if d_u8 else None, C.c_void_p(d_f32) if d_f32 else None,
                                                int(plane_stride), C.c_void_p(stream) if stream else None))
+
+    def render_sequence(self, params, x0, x1, n, d_u8=None, d_f32=None, plane_stride=None, frame_stride=None, cameras=None,
+                        streams=None, frames_per_launch=0):
+        """n frames into device memory with ONE call (rt_render_sequence): frame i at d_u8 + i*frame_stride bytes /
+        d_f32 + i*frame_stride floats.  cameras=None: n frames of the current camera, `frames_per_launch` of them per launch
+        (one launch's frames share a grid), launch g on streams[g % len(streams)].  cameras = float64 (n, 12) array of
+        (origin, rotation) rows: one launch per frame, frame i on streams[i % len(streams)]."""
+        if plane_stride is None:
+            plane_stride = (int(x1) - int(x0)) * self.h
+        if frame_stride is None:
+            frame_stride = 3 * int(plane_stride)
+        cam = None
+        if cameras is not None:
+            cam = np.ascontiguousarray(cameras, dtype=np.float64).reshape(-1, 12)
+            if cam.shape[0] != int(n):
+                raise ValueError(f"cameras must hold {n} rows of 12 doubles, got {cam.shape}")
+            self.generation["camera"] += 1
+        sv = tuple(int(s_) for s_ in streams) if streams else ()
+        if getattr(self, "_seq_streams_key", None) != sv:       # the ctypes array of handles is built once per set of streams
+            self._seq_streams_key = sv
+            self._seq_streams = (C.c_void_p * len(sv))(*sv) if sv else None
+        self._check(self._lib.rt_render_sequence(self._ctx, C.byref(params), int(x0), int(x1), int(n),
+                                                 C.c_void_p(d_u8) if d_u8 else None, C.c_void_p(d_f32) if d_f32 else None,
+                                                 int(plane_stride), int(frame_stride),
+                                                 cam.ctypes.data_as(C.POINTER(C.c_double)) if cam is not None else None,
+                                                 self._seq_streams, len(sv), int(frames_per_launch)))
 
     def sync(self, stream=None):
         """Wait for the context's stream, or for `stream` (a handle from stream_create / a hipStream_t address)."""

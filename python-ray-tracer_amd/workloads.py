@@ -66,6 +66,20 @@ STOCHASTIC = {"c5_7680x4320_s256_d8_spp4": dict(spp=4, seed=1)}
 HEADLINE = "c2_1920x1080_s8_d3"
 
 
+def camera_path(n, period=240):
+    """float64 (n, 12): origin[3] + rotation[9] per frame of a camera that moves with EVERY frame around the reference
+    driver's pose (main.py:24) — position on a small loop, pitch and yaw swinging a few degrees — for bench.py's `dynamic`
+    block and the moving-camera parity tests (README.md:23 "real-time display"; scene/camera.py:8-16)."""
+    from .scene.rotation import euler_rotation
+    out = np.empty((n, 12), np.float64)
+    for i in range(n):
+        t = 2.0 * np.pi * i / period
+        out[i, 0:3] = [CAMERA["position"][0] + 0.30 * np.sin(t), CAMERA["position"][1] + 0.25 * np.sin(2 * t),
+                       CAMERA["position"][2] + 0.10 * (1.0 - np.cos(t))]
+        out[i, 3:12] = euler_rotation(1.5 * np.sin(3 * t), CAMERA["euler"][1] + 2.0 * np.sin(t), 3.0 * np.sin(2 * t)).reshape(9)
+    return out
+
+
 def build(name):
     """-> dict(w, h, depth, aa, spheres, lights, planes, camera, rays)"""
     w, h, depth, aa, make, rays = CONFIGS[name]

@@ -304,3 +304,88 @@ def test_sequence_pipeline_without_a_group():
         pipe.submit(lambda u8, f32, stream, i=i: (u8.fill_(i), f32.fill_(float(i))))
     pipe.drain()
     assert int(pipe.last_slab()[0, 0, 0]) == 4 and pipe.index == 5
+
+
+def _frames_worker(rank, world, port, batch, nframes, chunks, out_path, rotate):
+    """SequencePipeline.submit_frames (whole batches per callback, what bench.py drives with rt_render_sequence) with
+    gather_f32=True: the float32 pre-clip planes are assembled as well as the uint8 frames (round-2 review: at N > 1 only the
+    byte frame could be checked)."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from python_ray_tracer_amd.distributed import weighted_slab_bounds, SequencePipeline
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = load_frame("c1_128")
+    w, h = 128, 128
+    bounds = weighted_slab_bounds([1.0 + 2.0 * (i >= 6) for i in range(16)], w, world)      # unequal slabs: padded gathers
+    x0, x1 = bounds[rank]
+    got8, got32 = {}, {}
+
+    def on_frames(first, frames, count, frames32):
+        for j in range(count):
+            got8[first + j] = frames[j].numpy().copy()
+            got32[first + j] = frames32[j].numpy().copy()
+    pipe = SequencePipeline(w, h, x1 - x0, torch.device("cpu"), dist, dst=0, streams=2, frames_per_gather=batch,
+                            want_f32=True, on_frames=on_frames, bounds=bounds, rotate_root=rotate, gather_f32=True)
+    state = {"next": 0}
+
+    def launch_seq(u8, f32, nf, stream):
+        assert stream is None and tuple(u8.shape) == (nf, 3, pipe.ws_pad, h) and tuple(f32.shape) == (nf, 3, pipe.ws_pad, h)
+        for j in range(nf):
+            i = state["next"]
+            state["next"] += 1
+            r = orc.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, i % 3, False,
+                           raygen=raygen_closed_form(w, h, 45.0), x0=x0, x1=x1, want=("u8", "f32"), nthreads=2)
+            u8[j][:, : x1 - x0].copy_(torch.from_numpy(np.ascontiguousarray(r["u8"][:, x0:x1])))
+            f32[j][:, : x1 - x0].copy_(torch.from_numpy(np.ascontiguousarray(r["f32"][:, x0:x1])))
+    made = []
+    for c in chunks:
+        made += pipe.submit_frames(launch_seq, c)
+    pipe.drain()
+    assert sum(nf for _, nf in made) == nframes == sum(chunks) and all(nf <= batch for _, nf in made)
+    mine = sorted(got8)
+    if not rotate:
+        assert mine == (list(range(nframes)) if rank == 0 else []), (rank, mine)
+    np.savez(out_path + f".rank{rank}.npz", **{f"u{i}": v for i, v in got8.items()}, **{f"f{i}": v for i, v in got32.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch,chunks,rotate", [(2, 3, (3, 3, 2), False), (2, 4, (6, 5), True), (3, 2, (1, 4), False)])
+def test_submit_frames_with_float32_assembly(tmp_path, oracle, world, batch, chunks, rotate):
+    """world-size 2 and 3 on gloo: the assembled float32 frame equals the single-process one bit for bit (and so does the
+    uint8 one), for whole and partly filled batches, fixed and rotating roots."""
+    import torch.multiprocessing as mp
+    nframes = sum(chunks)
+    out = str(tmp_path / "frames")
+    mp.spawn(_frames_worker, args=(world, _free_port(), batch, nframes, chunks, out, rotate), nprocs=world, join=True)
+    got = {}
+    for r_ in range(world):
+        got.update(np.load(out + f".rank{r_}.npz"))
+    g = load_frame("c1_128")
+    refs = [oracle.render(128, 128, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], 0.0, 0.6, 0.3, d, False,
+                          raygen=raygen_closed_form(128, 128, 45.0), want=("u8", "f32")) for d in range(3)]
+    for i in range(nframes):
+        assert np.array_equal(got[f"u{i}"], refs[i % 3]["u8"]), f"uint8 frame {i}"
+        assert np.array_equal(got[f"f{i}"], refs[i % 3]["f32"]), f"float32 frame {i}"
+
+
+def test_submit_frames_without_a_group():
+    """No process group: batches of frames_per_launch frames cycle through per-stream batch buffers."""
+    import torch
+    from python_ray_tracer_amd.distributed import SequencePipeline
+    pipe = SequencePipeline(16, 8, 16, torch.device("cpu"), None, streams=3, want_f32=True, frames_per_launch=4)
+    seen = []
+
+    def launch_seq(u8, f32, nf, stream):
+        seen.append(nf)
+        for j in range(nf):
+            u8[j].fill_(len(seen)); f32[j].fill_(float(len(seen)))
+    made = pipe.submit_frames(launch_seq, 10)
+    pipe.drain()
+    assert seen == [4, 4, 2] and [nf for _, nf in made] == seen and pipe.index == 10
+    assert int(pipe.last_slab()[0, 0, 0]) == 3
+    pipe.submit_frames(launch_seq, 3)                      # continues inside the open batch: 2 frames fill it, 1 opens the next
+    assert seen == [4, 4, 2, 2, 1]

@@ -879,3 +879,219 @@ def test_workload_ray_counts_are_the_device_counters(renderer, name):
     finally:
         renderer.free(d8)
     assert st["closest_queries"] == wl["rays"]["closest"] and st["shadow_traced"] + st["shadow_skipped"] == wl["rays"]["shadow"]
+
+
+# ---- round 3: rt_render_sequence, scene changes with frames in flight, the XCD-affine order --------------------------
+
+def test_render_sequence_every_frame_is_the_golden(renderer):
+    """rt_render_sequence (main.py:41-47 launches frame after frame): n frames of the headline scene with ONE call —
+    launches of several frames each, a partly filled last launch, one / three streams, uint8 and float32 — every frame of
+    every batch must be the reference's frame.  The first calls measure the tile costs frame by frame (single launches),
+    the later ones run whole batches per launch (launches < frames in rt_stats)."""
+    import hashlib
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+    n = 11
+    d8, d32 = renderer.malloc(n * 3 * w * h), renderer.malloc(n * 12 * w * h)
+    streams = [renderer.stream_create() for _ in range(3)]
+    try:
+        for fpl, strs, want32 in ((4, streams, True), (0, None, False), (11, streams[:1], True), (1, streams, False)):
+            renderer.reset_stats()
+            zero = np.zeros(n * 3 * w * h, np.uint8)
+            renderer.h2d(d8, zero)
+            renderer.render_sequence(p, 0, w, n, d8, d32 if want32 else None, w * h, 3 * w * h, None, strs, fpl)
+            for s_ in streams:
+                renderer.sync(s_)
+            renderer.sync()
+            got = np.empty((n, 3, w, h), np.uint8)
+            renderer.d2h(got, d8)
+            for i in range(n):
+                assert np.array_equal(got[i], g["frame_u8"]), (fpl, i, int((got[i] != g["frame_u8"]).any(axis=0).sum()))
+            if want32:
+                f32 = np.empty((n, 3, w, h), np.float32)
+                renderer.d2h(f32, d32)
+                for i in (0, n // 2, n - 1):
+                    assert hashlib.sha256(f32[i].tobytes()).hexdigest() == str(g["sha256_rgb32"]), (fpl, i)
+            st = renderer.stats()
+            assert st["frames"] == n
+        assert st["launches"] == n                                   # fpl = 1: a launch per frame
+        renderer.reset_stats()
+        renderer.render_sequence(p, 0, w, n, d8, None, w * h, 3 * w * h, None, streams, 4)
+        for s_ in streams:
+            renderer.sync(s_)
+        st = renderer.stats()
+        assert st["frames"] == n and st["launches"] == 3 and st["launches_settled"] == 3, st     # 4 + 4 + 3 frames
+    finally:
+        for s_ in streams:
+            renderer.stream_destroy(s_)
+        renderer.free(d8); renderer.free(d32)
+
+
+@pytest.mark.parametrize("aa", [0, 1])
+def test_render_sequence_slab_and_aa(renderer, oracle, aa):
+    """A column slab rendered in place inside full frames (plane_stride = w*h, frame_stride = 3*w*h), with and without
+    the 9-tap mode (which runs lattice + resolve per frame), against the oracle."""
+    g = load_frame("default_128_d3")
+    w, h, rg = _setup(renderer, g)
+    p = renderer.params(float(g["amb"]), float(g["lamb"]), float(g["refl"]), 2, aa)
+    ref = oracle.render(w, h, g["cam_origin"], g["cam_rot"], g["spheres"], g["lights"], g["planes"], float(g["amb"]), float(g["lamb"]),
+                        float(g["refl"]), 2, bool(aa), raygen=rg, want=("u8", "f32"))
+    n, x0, x1 = 5, 40, 99
+    d8, d32 = renderer.malloc(n * 3 * w * h), renderer.malloc(n * 12 * w * h)
+    try:
+        for rep in range(3):                                         # measuring, measuring, settled
+            renderer.h2d(d8, np.zeros(n * 3 * w * h, np.uint8))
+            renderer.render_sequence(p, x0, x1, n, d8 + x0 * h, d32 + 4 * x0 * h, w * h, 3 * w * h, None, None, 3)
+            renderer.sync()
+            got8, got32 = np.empty((n, 3, w, h), np.uint8), np.empty((n, 3, w, h), np.float32)
+            renderer.d2h(got8, d8); renderer.d2h(got32, d32)
+            for i in range(n):
+                assert np.array_equal(got8[i][:, x0:x1], ref["u8"][:, x0:x1]), (rep, i)
+                assert np.array_equal(got32[i][:, x0:x1], ref["f32"][:, x0:x1]), (rep, i)
+                assert not got8[i][:, :x0].any() and not got8[i][:, x1:].any()
+    finally:
+        renderer.free(d8); renderer.free(d32)
+    import python_ray_tracer_amd as pkg
+    with pytest.raises(pkg.RenderError):
+        renderer.render_sequence(p, 0, w, 2, 1, None, w * h, 2 * w * h)            # frame_stride < 3 planes
+    with pytest.raises(pkg.RenderError):
+        renderer.render_sequence(p, 0, w, -1, 1, None, w * h, 3 * w * h)
+
+
+@pytest.mark.parametrize("remeasure", ["24", "2", "0"])
+def test_moving_camera_sequence(monkeypatch, oracle, remeasure):
+    """rt_render_sequence with a camera per frame (bench.py's `dynamic` block; README.md:23, scene/camera.py:8-16): position
+    and rotation change with EVERY frame, frames round-robin on three streams.  The dispatch order measured under an earlier
+    camera is kept for MI355RT_REMEASURE launches and then measured again; cull tables follow the camera position.  Every
+    frame must be its own oracle frame, uint8 and float32."""
+    import python_ray_tracer_amd as pkg
+    from python_ray_tracer_amd import workloads
+    monkeypatch.setenv("MI355RT_REMEASURE", remeasure)
+    wl = workloads.build("c2_1920x1080_s8_d3")
+    w, h = 160, 96
+    from python_ray_tracer_amd.scene import Camera
+    rg = Camera((w, h), [0, 0, 0], [0, 0, 0], fov=45.0).raygen()
+    n = 14
+    cams = workloads.camera_path(n, period=9)
+    r = pkg.Renderer(0)
+    try:
+        r.set_scene(wl["spheres"], wl["lights"], wl["planes"])
+        r.set_raygen(w, h, *rg)
+        p = r.params(wl["amb"], wl["lamb"], wl["refl"], wl["depth"], 0)
+        streams = [r.stream_create() for _ in range(3)]
+        d8, d32 = r.malloc(n * 3 * w * h), r.malloc(n * 12 * w * h)
+        for rep in range(2):
+            r.render_sequence(p, 0, w, n, d8, d32, w * h, 3 * w * h, cams, streams)
+            for s_ in streams:
+                r.sync(s_)
+            got8, got32 = np.empty((n, 3, w, h), np.uint8), np.empty((n, 3, w, h), np.float32)
+            r.d2h(got8, d8); r.d2h(got32, d32)
+            for i in range(n):
+                ref = oracle.render(w, h, cams[i, 0:3], cams[i, 3:12].reshape(3, 3), wl["spheres"], wl["lights"], wl["planes"],
+                                    wl["amb"], wl["lamb"], wl["refl"], wl["depth"], False, raygen=rg, want=("u8", "f32"))
+                assert np.array_equal(got8[i], ref["u8"]), (rep, i)
+                assert np.array_equal(got32[i], ref["f32"]), (rep, i)
+        st = r.stats()
+        assert st["frames"] == 2 * n and st["table_builds"] >= n
+        if remeasure == "24":
+            assert st["launches_measuring"] <= 3, st             # the first frames only: the order is kept while the camera moves
+        for s_ in streams:
+            r.stream_destroy(s_)
+        r.free(d8); r.free(d32)
+    finally:
+        r.close()
+
+
+def test_scene_changes_with_frames_in_flight(renderer, oracle):
+    """rt_set_scene between launches that are still in flight on other streams (an animation that moves its spheres): every
+    launch keeps the scene buffer it was queued with (a ring inside the context), so each frame must be the oracle's frame
+    of ITS scene — more scene changes than the ring has buffers, frames large enough to still be running when the next
+    scene arrives."""
+    g = load_frame("default_128_d3")
+    w, h = 512, 384
+    from python_ray_tracer_amd.scene import Camera
+    cam = Camera((w, h), [-2, 0, 2.0], [0, -30, 0], fov=45.0)
+    rg = cam.raygen()
+    renderer.set_camera(cam.position, cam.rotation)
+    renderer.set_raygen(w, h, *rg)
+    p = renderer.params(0.05, 0.6, 0.3, 3, 0)
+    nscenes = 7
+    scenes = []
+    for i in range(nscenes):
+        sp = np.array(g["spheres"], np.float32).copy()
+        sp[0] += 0.15 * i; sp[1, ::2] -= 0.2 * i; sp[3] *= (1.0 + 0.05 * i)
+        sp = sp[:, : sp.shape[1] - (i % 3)]                       # the sphere count changes too
+        scenes.append(sp)
+    streams = [renderer.stream_create() for _ in range(3)]
+    bufs = [renderer.malloc(3 * w * h) for _ in range(nscenes)]
+    try:
+        for i in range(nscenes):                                     # no waiting between scene change and launch
+            renderer.set_scene(scenes[i], g["lights"], g["planes"])
+            renderer.render_device(p, 0, w, bufs[i], None, w * h, stream=streams[i % 3])
+        for s_ in streams:
+            renderer.sync(s_)
+        for i in range(nscenes):
+            got = np.empty((3, w, h), np.uint8)
+            renderer.d2h(got, bufs[i])
+            ref = oracle.render(w, h, cam.position, cam.rotation, scenes[i], g["lights"], g["planes"], 0.05, 0.6, 0.3, 3, False,
+                                raygen=rg, want=("u8",))["u8"]
+            assert np.array_equal(got, ref), f"scene {i}: {(got != ref).any(axis=0).sum()} pixels differ"
+    finally:
+        for s_ in streams:
+            renderer.stream_destroy(s_)
+        for b in bufs:
+            renderer.free(b)
+
+
+def test_pinned_arrays_outlive_their_renderer():
+    """Page-locked arrays from Renderer.host_array() belong to the arrays: closing the Renderer must not free memory a
+    numpy view still points at (round-2 advice), and a DeviceNDArray never hands a closed context's pointer to a new one."""
+    import python_ray_tracer_amd as pkg
+    from python_ray_tracer_amd import cuda
+    g = load_frame("default_128_d3")
+    r = pkg.Renderer(0)
+    w, h, _ = _setup(r, g)
+    a8, _ = r.host_arrays(False, pinned=True)
+    r.render_into(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, a8, refl_pow=g["refl_pow"])
+    view = a8[1]
+    r.close()
+    assert np.array_equal(a8, g["frame_u8"]) and np.array_equal(view, g["frame_u8"][1])      # still readable
+    a8[:] = 7                                                                                   # ... and writable
+    del a8, view
+    # facade: result handle used across cuda.close()
+    cuda.close()
+    from python_ray_tracer_amd.ray_tracing import render
+    from python_ray_tracer_amd.scene import Camera
+    cam = Camera((w, h), [-2, 0, 2.0], [0, -30, 0], fov=float(g["fov"]))
+    res = cuda.to_device(np.zeros((3, w, h), np.uint8))
+    args = (cuda.to_device(cam.generate_pixel_locations()), res, cuda.to_device(np.array(g["cam_origin"])), cuda.to_device(np.array(g["cam_rot"])),
+            cuda.to_device(g["spheres"]), cuda.to_device(g["lights"]), cuda.to_device(g["planes"]),
+            float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), False)
+    render[(w // 8, h // 8), (8, 8)](*args)
+    first = res.copy_to_host()
+    cuda.close()                                                     # the context (and res's device buffer) is gone
+    render[(w // 8, h // 8), (8, 8)](*args)                          # a new context: res gets a new buffer
+    assert np.array_equal(res.copy_to_host(), first)
+    cuda.close()
+
+
+def test_tile_stats_through_the_chunked_host_path(renderer):
+    """rt_render splits a 1080p frame into four column chunks (separate launches): every chunk must record its tiles at
+    the FRAME's tile indices (round-2 advice: the chunks used to overwrite each other from index 0)."""
+    g = load_frame("c2_1080p")
+    w, h, _ = _setup(renderer, g)
+    tiles_y = (h + 7) // 8
+    ntiles = ((w + 7) // 8) * tiles_y
+    d = renderer.malloc(4 * ntiles)
+    try:
+        renderer.h2d(d, np.zeros(ntiles, np.uint32))
+        renderer.set_tile_stats(d)
+        u8, _ = renderer.render(float(g["amb"]), float(g["lamb"]), float(g["refl"]), int(g["depth"]), 0, refl_pow=g["refl_pow"])
+        cyc = np.empty(ntiles, np.uint32)
+        renderer.d2h(cyc, d)
+        assert np.array_equal(u8, g["frame_u8"])
+        assert (cyc > 0).all(), f"{(cyc == 0).sum()} of {ntiles} tiles recorded nothing"
+    finally:
+        renderer.set_tile_stats(None)
+        renderer.free(d)
