@@ -119,9 +119,10 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, help="one of python_ray_tracer_amd.workloads.CONFIGS")
-    ap.add_argument("--streams", type=int, default=3, help="streams the frames are queued on round-robin (1 = strictly serial)")
+    ap.add_argument("--streams", type=int, default=None, help="streams the launches are queued on round-robin; default 1 on one GPU (a launch "
+                    "renders --frames-per-launch frames in one grid: they overlap inside the launch) and 3 with a gather")
     ap.add_argument("--frames-per-gather", type=int, default=8, help="N > 1: frames whose slabs travel to rank 0 in one gather")
-    ap.add_argument("--frames-per-launch", type=int, default=8, help="frames one kernel launch renders (rt_render_sequence); with a gather: = --frames-per-gather; 0 = one Python call and one launch per frame, as in round 2")
+    ap.add_argument("--frames-per-launch", type=int, default=16, help="frames one kernel launch renders (rt_render_sequence); with a gather: = --frames-per-gather; 0 = one Python call and one launch per frame, as in round 2")
     ap.add_argument("--gather", choices=("u8", "f32"), default="u8", help="N > 1: assemble the uint8 frames only, or the float32 pre-clip planes as well (a second gather per batch)")
     ap.add_argument("--no-dynamic", action="store_true", help="skip the moving-camera pass behind the timed region (dynamic)")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 exchange structure on one GPU (world-size-1 RCCL group)")
@@ -174,6 +175,8 @@ def main():
     # Column slabs: equal widths to start with; with N > 1 the boundaries are then moved until the ranks' MEASURED slab
     # times agree (sky columns are cheap, the sphere cluster is not: equal widths leave the slowest rank 23 % above
     # the mean at N = 8, and the frame is as slow as its slowest slab).  Setup, like the uploads: not timed.
+    if a.streams is None:
+        a.streams = 3 if (world > 1 or a.force_gather) else 1
     bounds = [slab_bounds(w, world, q) for q in range(world)]
     balance = None
     if world > 1 and a.balance_rounds > 0:
@@ -188,8 +191,8 @@ def main():
     # to rank 0 in ONE gather (a collective costs tens of microseconds however small it is; a 240-column slab
     # renders in less), issued on a separate stream, two exchanges in flight: batch i is gathered and assembled
     # while batch i+1 renders.
-    NS = max(1, a.streams)
     use_gather = world > 1 or a.force_gather
+    NS = max(1, a.streams)
     if a.force_gather and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
@@ -315,7 +318,7 @@ def main():
         done.sort()
         need = min(max(16 * NS, 32), max(1, sum(nf for _, nf in done[1:])))
         j, acc = 0, 0
-        for i in range(1, len(done)):
+        for i in range(1, len(done) if len(done) >= 4 * NS else 0):      # (a handful of launches complete together: no statistic)
             acc += done[i][1]
             while acc - done[j + 1][1] >= need and j + 1 < i:
                 j += 1
@@ -434,15 +437,16 @@ def main():
                                       cams[c0:c0 + nf], handles, 0)
                     done_ += nf
             dyn(max(a.warmup, 4 * chunk))
+            dsteps = max(a.steps, 10 * chunk)           # one launch per frame: a short region would time the pipeline's fill and drain
             fence()
             td = time.perf_counter()
-            dyn(a.steps, start=chunk)
+            dyn(dsteps, start=chunk)
             td_sub = time.perf_counter()
             fence()
-            dyn_ms = (time.perf_counter() - td) / a.steps * 1e3
+            dyn_ms = (time.perf_counter() - td) / dsteps * 1e3
             st = r.stats()
             dynamic = {"ms_per_step": round(dyn_ms, 5), "ratio_to_static": round(dyn_ms / ms_per_step, 4),
-                       "host_submit_ms_per_step": round((td_sub - td) / a.steps * 1e3, 5), "streams": NS,
+                       "host_submit_ms_per_step": round((td_sub - td) / dsteps * 1e3, 5), "streams": NS, "steps": dsteps,
                        "camera": "python_ray_tracer_amd.workloads.camera_path: position, pitch, yaw and roll change with every frame",
                        "note": "one launch per frame (every frame has its own camera and cull tables); frames bit-equal to the oracle: "
                                "tests/test_gpu_parity.py::test_moving_camera_sequence"}

@@ -46,6 +46,10 @@ struct rt_ctx {
     int render_chunks = 4;            // MI355RT_CHUNKS overrides (1 = one launch, one copy)
     int order_group = -1;             // MI355RT_ORDER_GROUP: log2 of the blocks per XCD-affine dispatch group (0..6; 0 = every block on its
                                       // own; default -1 = groups of 16 tiles)
+    int seq_order = -1;               // MI355RT_SEQ_ORDER: 1 / 0 = all but the last frame of a multi-frame launch in the XCD's tile order / every
+                                      // frame longest-first; default -1 = tile order for the two-wave kernels (small flat scenes: headline
+                                      // 0.1050 ms either way, writes 31.8 instead of 38.7 MB per frame), longest-first for the four-wave ones
+                                      // (config 4: 0.734 against 0.785 ms — runs of cheap sky tiles starve the dispatcher in tile order)
     int remeasure = 24;               // MI355RT_REMEASURE: launches a dispatch order measured under an older camera is kept for before
                                       // the tile costs are measured again (a moving camera; any order renders the same frame)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
@@ -469,8 +473,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         const size_t words = (size_t)grid * sizeof(unsigned);
         int rc = ensure(ctx, f.cost, words);
         if (rc == RT_OK) rc = ensure(ctx, f.btmp, words);
-        if (rc == RT_OK) rc = ensure(ctx, f.order[0], words);
-        if (rc == RT_OK) rc = ensure(ctx, f.order[1], words);
+        if (rc == RT_OK) rc = ensure(ctx, f.order[0], 2 * words);     // longest-first order, then the tile-order one (order_kernel)
+        if (rc == RT_OK) rc = ensure(ctx, f.order[1], 2 * words);
         if (rc == RT_OK) rc = ensure(ctx, f.gtmp, words + sizeof(unsigned));
         if (rc != RT_OK) return rc;
         for (auto &e : f.fence) {                              // (recorded at the last switch: complete long ago)
@@ -480,7 +484,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         f.fence.clear();
         k.cost = (unsigned *)f.cost.p;
     }
-    k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride;
+    k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride; k.seq_offset = (ctx->seq_order < 0 ? wpw == 2 : ctx->seq_order != 0) ? (int)grid : 0;
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid * (unsigned)nframes), dim3(wgt), args, lds, stream));
     ctx->stats.launches++;
@@ -533,6 +537,7 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_REMEASURE")) ctx->remeasure = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("MI355RT_SEQ_ORDER")) ctx->seq_order = std::atoi(e) != 0 ? 1 : 0;
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
     hipError_t s;
     if ((s = hipSetDevice(device)) != hipSuccess || (s = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||

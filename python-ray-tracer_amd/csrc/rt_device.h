@@ -84,7 +84,10 @@ struct KParams {
     unsigned *tile_cycles;     // or nullptr: per-tile wave cycles of this launch (rt_set_tile_stats)
     unsigned *cost;            // or nullptr: scheduler feedback — a measuring launch stores every tile block's cost (wave cycles / 4,
                                // summed over the block's waves); order_kernel turns them into the next launches' dispatch order
-    const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs
+    const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs (XCD-affine, longest
+                               // first inside every XCD); order + bpf: the same XCD assignment in plain tile order, which all but the
+                               // last frame of a multi-frame launch use (order_kernel)
+    int seq_offset;            // bpf, or 0 to dispatch every frame of a multi-frame launch longest-first (MI355RT_SEQ_ORDER=0)
     int nframes, bpf;          // frames rendered by this launch (rt_render_sequence) and workgroups per frame: workgroup b renders
                                // block order[b % bpf] of frame b / bpf into the outputs + (b / bpf) * frame_stride elements
     long long frame_stride;
@@ -1340,9 +1343,17 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // Any permutation renders every tile exactly once; only the length of the launch's tail depends on it.
     // A launch may carry several frames of the same scene and camera (rt_render_sequence): workgroups [f bpf, (f+1) bpf)
     // render frame f, each frame in the same order, so one frame's last workgroups run beside the next frame's first.
+    // Only the LAST frame of a launch decides how raggedly the launch ends, so only it is dispatched longest-first; the
+    // frames before it run every XCD's blocks in tile order, neighbours in y back to back on the XCD that owns their group:
+    // the 128-byte lines they share are completed in that L2 within microseconds.
     int bid = (int)blockIdx.x;
-    if (p.nframes > 1) bid -= (bid / p.bpf) * p.bpf;
-    const int block = p.order ? (int)p.order[bid] : bid;
+    const unsigned *ord = p.order;
+    if (p.nframes > 1) {
+        const int frame = bid / p.bpf;
+        bid -= frame * p.bpf;
+        if (ord && frame < p.nframes - 1) ord += p.seq_offset;
+    }
+    const int block = ord ? (int)ord[bid] : bid;
     const int tile = block * WAVES_PER_WG + wave;
     if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
     const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1475,7 +1486,13 @@ __global__ __launch_bounds__(256) void aa_resolve_kernel(const KParams p)
 //      on one stream); here the order inside an XCD is as fine as the plain longest-first order.
 // The groups that do not fill a row of eight and the short group at the end of the frame share the positions behind those
 // rows, longest first.  The output is a permutation of [0, nblocks) by construction; any permutation renders the same frame.
-// gtmp: nblocks / 2^gshift + 1 words, btmp: nblocks words of scratch.
+//   3. a second permutation, order[nblocks ..], keeps the XCD assignment of step 1 but runs every XCD's blocks in plain tile
+//      order (group after group, the blocks of a group back to back).  All but the last frame of a multi-frame launch use
+//      it: in the middle of a launch every CU is busy whatever the order, and blocks that share output lines then follow
+//      each other on their XCD within microseconds (step 2's order scatters a group's blocks over the XCD's whole list:
+//      measured 37 MB of writes per headline frame instead of 41 for 31 MB of pixels; tile order inside the XCD: see
+//      profiles/r03_order_group_sweep.txt).
+// gtmp: nblocks / 2^gshift + 1 words, btmp: nblocks words of scratch; order: 2 nblocks words.
 __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__restrict__ cost, unsigned *__restrict__ gtmp,
                                                                unsigned *__restrict__ btmp, unsigned *__restrict__ order, int nblocks, int gshift)
 {
@@ -1523,6 +1540,42 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__
         gtmp[g] = q < rows ? (unsigned)((q & 1) ? ORDER_XCDS - 1 - c : c) : (unsigned)ORDER_XCDS;
     }
     __syncthreads();
+    const unsigned tail = (unsigned)(ORDER_XCDS * rows * gb);                // first position behind the rows
+    {   // 3. the same XCD assignment in tile order: thread i owns the groups [i per, (i + 1) per); for every class an exclusive
+        // scan over the threads of how many of its groups they own gives each group its rank within its class
+        unsigned *seq = order + nblocks;
+        const int per = (full + ORDER_THREADS - 1) / ORDER_THREADS;
+        const int g0 = i * per < full ? i * per : full, g1 = g0 + per < full ? g0 + per : full;
+        unsigned base[ORDER_XCDS + 1];
+        for (int c = 0; c <= ORDER_XCDS; ++c) {
+            unsigned v = 0;
+            for (int g = g0; g < g1; ++g) v += gtmp[g] == (unsigned)c ? 1u : 0u;
+            unsigned incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            __syncthreads();
+            if (lane == 63) scan[wv] = incl;
+            __syncthreads();
+            unsigned b0 = 0;
+            for (int w = 0; w < wv; ++w) b0 += scan[w];
+            base[c] = b0 + incl - v;
+        }
+        for (int g = g0; g < g1; ++g) {
+            const unsigned c = gtmp[g];
+            unsigned jg = 0;
+#pragma unroll
+            for (int cc = 0; cc <= ORDER_XCDS; ++cc) if (c == (unsigned)cc) jg = base[cc]++;
+            for (int k = 0; k < gb; ++k) {
+                const unsigned j = jg * (unsigned)gb + (unsigned)k;
+                seq[c < (unsigned)ORDER_XCDS ? ORDER_XCDS * j + c : tail + j] = (unsigned)((g << gshift) + k);
+            }
+        }
+        for (int b = (full << gshift) + i; b < nblocks; b += ORDER_THREADS) seq[b] = (unsigned)b;    // the short group: last, in place
+    }
+    __syncthreads();
     for (int k = i; k < (ORDER_XCDS + 1) * ORDER_BUCKETS; k += ORDER_THREADS) hist[k] = 0u;
     __syncthreads();
     // 2. blocks by their own cost, per XCD
@@ -1533,7 +1586,6 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__
         btmp[b] = (x << 28) | ((unsigned)bkt << 18) | atomicAdd(&hist[x * ORDER_BUCKETS + bkt], 1u);     // nblocks < 2^18 (host)
     }
     scan_classes(ORDER_XCDS + 1);
-    const unsigned tail = (unsigned)(ORDER_XCDS * rows * gb);                // first position behind the rows
     for (int b = i; b < nblocks; b += ORDER_THREADS) {
         const unsigned s = btmp[b], x = s >> 28;
         const unsigned j = hist[x * ORDER_BUCKETS + ((s >> 18) & 1023u)] + (s & 0x3FFFFu);

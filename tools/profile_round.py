@@ -53,10 +53,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--trace-steps", type=int, default=1000)
     ap.add_argument("--trace-warmup", type=int, default=50)
-    ap.add_argument("--pmc-steps", type=int, default=20)
+    ap.add_argument("--pmc-steps", type=int, default=32)
     ap.add_argument("--sets", default="sq1,sq2,sq3,sq4,fetch,write")
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--stamp", action="store_true")
@@ -67,7 +67,7 @@ def main():
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
     bench = os.path.join(REPO, "bench.py")
-    common = ["--streams", str(a.streams), "--no-cpu-baseline"] + (["--workload", a.workload] if a.workload else []) + (["--flags", str(a.flags)] if a.flags else [])
+    common = ["--streams", str(a.streams), "--no-cpu-baseline", "--no-dynamic"] + (["--workload", a.workload] if a.workload else []) + (["--flags", str(a.flags)] if a.flags else [])
 
     # 1. kernel trace of the bench command, without its serial pass and host-path timing: every render launch in the
     #    trace is then of the kind the timed region times (pre-heat, warm-up and timed steps on --streams streams), so
@@ -93,14 +93,20 @@ def main():
                  "--steps", str(a.pmc_steps), "--warmup", "3", "--preheat-ms", "0", "--no-serial", "--no-host-path"] + common,
                 os.path.join(out, f"pmc_{name}.log"))
             f = glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True)[0]
+            # a launch renders one or several frames (rt_render_sequence): its grid is frames x workgroups per frame, and the
+            # run always holds single-frame launches of the same kernel (the first launches of a geometry), so
+            # frames = Grid_Size / smallest Grid_Size.  Counters are reported per FRAME: sum over launches / sum of frames.
             per = collections.defaultdict(lambda: collections.defaultdict(list))
             for row in csv.DictReader(open(f)):
                 if "render_kernel" in row["Kernel_Name"]:
-                    per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    per[row["Kernel_Name"]][row["Counter_Name"]].append((float(row["Counter_Value"]), int(row.get("Grid_Size") or 1)))
             if per:
-                kname = max(per, key=lambda k: max(len(v) for v in per[k].values()))     # the dominant instantiation
+                kname = max(per, key=lambda k: sum(g for _, g in next(iter(per[k].values()))))     # the dominant instantiation (by work)
                 for cn, vals in per[kname].items():
-                    summary[cn] = {"launches": len(vals), "mean_per_launch": round(sum(vals) / len(vals), 2)}
+                    g1 = min(g for _, g in vals)
+                    frames = sum(round(g / g1) for _, g in vals)
+                    summary[cn] = {"launches": len(vals), "frames": frames, "mean_per_launch": round(sum(v for v, _ in vals) / frames, 2),
+                                   "note": "mean_per_launch = per FRAME (a launch may render several)"}
                 summary["_kernel"] = kname
             shutil.rmtree(pdir, ignore_errors=True)
             print("pmc", name, "done", flush=True)
