@@ -50,6 +50,8 @@ struct rt_ctx {
                                       // frame longest-first; default -1 = tile order for the two-wave kernels (small flat scenes: headline
                                       // 0.1050 ms either way, writes 31.8 instead of 38.7 MB per frame), longest-first for the four-wave ones
                                       // (config 4: 0.734 against 0.785 ms — runs of cheap sky tiles starve the dispatcher in tile order)
+    int pool_lanes = 1;               // MI355RT_POOL=0: the round-2 lane-owned kernel (one wave per tile for the whole path) instead of the
+                                      // re-packing pool kernel (A/B)
     int remeasure = 24;               // MI355RT_REMEASURE: launches a dispatch order measured under an older camera is kept for before
                                       // the tile costs are measured again (a moving camera; any order renders the same frame)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
@@ -185,8 +187,13 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
 
 // instantiations with the lane-owned traversal (MODE 2: clustered scenes from lanes_min_spheres spheres on); workgroups of
 // 4, register variants only (their LDS image leaves no room for parked state)
-const void *lanes_variant(bool aa, bool lattice)
+constexpr int POOL_WPW = 8;   // wavefronts (tiles) per workgroup of rt::render_pool_kernel
+const void *lanes_variant(bool aa, bool lattice, bool pool)
 {
+    if (pool) {                // workgroups of 8 waves that re-pack their live rays between bounces (rt_device.h)
+        if (lattice) return (const void *)rt::render_pool_kernel<false, true, POOL_WPW>;
+        return aa ? (const void *)rt::render_pool_kernel<true, false, POOL_WPW> : (const void *)rt::render_pool_kernel<false, false, POOL_WPW>;
+    }
     if (lattice) return (const void *)rt::render_kernel<false, false, 4, false, true, 2>;
     return aa ? (const void *)rt::render_kernel<true, false, 4, false, false, 2> : (const void *)rt::render_kernel<false, false, 4, false, false, 2>;
 }
@@ -289,6 +296,7 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     k.aa = p->aa_mode; k.u8_rgb = (p->flags & RT_FLAG_U8_RGB) ? 1 : 0; k.u8_hwc = (p->flags & RT_FLAG_U8_HWC) ? 1 : 0;
     k.spp = p->spp; k.seed = p->seed;
     k.lanes_primary = ctx->lanes_primary;
+    k.pool_repack = std::getenv("MI355RT_POOL_REPACK") ? std::atoi(std::getenv("MI355RT_POOL_REPACK")) : 1;
     k.tiles_y = (ctx->h + rt::TILE - 1) / rt::TILE;
     const int tiles_x = (x1 - x0 + rt::TILE - 1) / rt::TILE;
     k.ntiles = tiles_x * k.tiles_y;
@@ -365,12 +373,14 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // (Round 2's bundle pre-cull, MODE 1/3, lost against these clusters at every measured size and was removed in round 3:
     // profiles/r02_variant_thresholds.txt.)
     const bool lanes = ctx->NC > 0 && ctx->S >= ctx->lanes_min_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    const int wpw = (image <= 4608 && !count && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
+    const bool pool = lanes && ctx->pool_lanes;
+    const int wpw = pool ? POOL_WPW : (image <= 4608 && !count && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt);
     const bool park = !count && !lanes && lds_park * (24 / wpw) <= 160 * 1024;
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, lanes && k.anchors > 0);
-    const void *fn = lanes ? lanes_variant(aa, lattice) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
+    const size_t lds = pool ? rt::lds_pool_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, wgt)
+                            : park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, lanes && k.anchors > 0);
+    const void *fn = lanes ? lanes_variant(aa, lattice, pool) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -379,8 +389,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         for (int v = 0; v < 4; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(v & 1, (v & 2) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (int v = 0; v < 3; ++v)
-            RT_HIP(ctx, hipFuncSetAttribute(lanes_variant(v == 1, v == 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 6; ++v)
+            RT_HIP(ctx, hipFuncSetAttribute(lanes_variant(v % 3 == 1, v % 3 == 2, v >= 3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_limit_set = lds;
     }
     if (count) {
@@ -403,7 +413,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const int gshift = ctx->order_group >= 0 ? ctx->order_group : (wpw == 2 ? 3 : 2);
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
-    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (lanes ? 32 : 0);
+    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (lanes ? 32 : 0);                     // (8 + 32: the pool kernel)
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
     if (!fsel && feedback) {                                   // a free slot, else the least recently used geometry
@@ -537,6 +547,7 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_REMEASURE")) ctx->remeasure = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("MI355RT_POOL")) ctx->pool_lanes = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI355RT_SEQ_ORDER")) ctx->seq_order = std::atoi(e) != 0 ? 1 : 0;
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
     hipError_t s;

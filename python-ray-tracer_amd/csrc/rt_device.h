@@ -87,6 +87,7 @@ struct KParams {
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs (XCD-affine, longest
                                // first inside every XCD); order + bpf: the same XCD assignment in plain tile order, which all but the
                                // last frame of a multi-frame launch use (order_kernel)
+    int pool_repack;           // render_pool_kernel: 0 = never re-pack (A/B: the cost of the lockstep alone)
     int seq_offset;            // bpf, or 0 to dispatch every frame of a multi-frame launch longest-first (MI355RT_SEQ_ORDER=0)
     int nframes, bpf;          // frames rendered by this launch (rt_render_sequence) and workgroups per frame: workgroup b renders
                                // block order[b % bpf] of frame b / bpf into the outputs + (b / bpf) * frame_stride elements
@@ -1441,6 +1442,194 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
             const int expected = (p.ntiles - block * WAVES_PER_WG < WAVES_PER_WG) ? p.ntiles - block * WAVES_PER_WG : WAVES_PER_WG;
             atomicAdd(&wgstat[0], cyc >> 2);
             if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel of the large clustered scenes (lane-owned traversal, MODE 2; from 161 spheres on): workgroups of WPW = 8
+// wavefronts that RE-PACK their surviving rays between bounces.
+//
+// A ray path ends when a bounce misses (trace.py:124-126), so after a few bounces a tile's wave runs with a fraction of its
+// lanes: measured on config 5 (round 2, one wave per tile for the whole path), the lanes alive per bounce were 1.00, 1.00,
+// 0.95, 0.85, 0.72, 0.57, 0.44, 0.34, 0.26 of the wave, and bounces 2-8 took 55 % of the frame for 25 % of its queries.
+// Here the 512 rays of a workgroup's eight tiles are a POOL: before every bounce the workgroup counts its live rays and,
+// when they fit fewer wavefronts than currently hold them, copies (origin, direction, slot) of every live ray through LDS
+// to the lowest lanes of the workgroup — order preserving, so neighbours stay neighbours — and the wavefronts left without
+// a ray sit the bounce out.  A ray's colour does not travel: it is accumulated in LDS under the ray's SLOT (the thread that
+// generated it, which owns the pixel and stores it at the end), in the reference's order — RGB += refl**(i+1) RGB_i is
+// sequential per path (trace.py:131), and every bounce is the same bounce for all rays of the workgroup, so the weight and
+// the cull anchor stay wave-uniform.  The same float64 operations on the same values: frames are bit-identical.
+// Eight waves per workgroup instead of four: the scene image (config 5: 40 KB) is staged once for twice as many rays, which
+// is what makes room for the colour slots, the exchange buffer and the parked direction (no scratch), at the same 16 waves
+// per CU.  Barriers: one per bounce for the count, four per re-pack (two passes of three doubles through one 12 KB buffer,
+// which is also where trace_bounce parks the incoming direction).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t lds_pool_bytes(int S, int P, int L, int NC, int anchors, bool aa, int wgt)
+{
+    return (lds_doubles(S, P, L) + (size_t)(aa ? 9 : 6) * wgt) * sizeof(double) + (size_t)wgt * sizeof(int) +
+           table_floats(S, NC, anchors, anchors > 0) * sizeof(float) + 16 + (size_t)(2 * (wgt / 64) + 4) * sizeof(unsigned);
+}
+
+template <bool AA, bool LAT, int WPW>
+__global__ __launch_bounds__(64 * WPW, RT_W_LANES) void render_pool_kernel(const KParams p)
+{
+    constexpr int WGT = 64 * WPW;
+    const int nrec = (int)lds_doubles(p.S, p.P, p.L);
+    double *accum = lds_raw + nrec;                    // [0, 3 WGT) colour by ray slot | [3 WGT, 6 WGT) parked direction / exchange | AA: [6 WGT, 9 WGT) tap sums
+    int *xslot = reinterpret_cast<int *>(accum + (AA ? 9 : 6) * WGT);
+    float *sph32 = reinterpret_cast<float *>(xslot + WGT);
+    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
+    const bool LANES = p.anchors > 0;                  // (as in render_kernel: with anchored tables the clusters' origin-form spheres stay in global memory)
+    float *tab = sph32 + tl.tab;
+    float *csph32 = LANES ? nullptr : sph32 + tl.csph32;
+    float *ctab = sph32 + tl.ctab;
+    float *cbox = sph32 + tl.cbox;
+    unsigned *wgstat = reinterpret_cast<unsigned *>(sph32 + (LANES ? tl.total_lanes : tl.total));   // {cycles, waves done, -, -}
+    volatile unsigned *pool = wgstat + 4;              // live rays per wave, two sets (bounce parity)
+    if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
+    {
+        for (int i = threadIdx.x; i < nrec; i += WGT) lds_raw[i] = p.scene[i];
+        const int nf4 = (int)((LANES ? tl.total_lanes : tl.total) / 4);
+        const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
+        f4 *dst = reinterpret_cast<f4 *>(sph32);
+        for (int i = threadIdx.x; i < nf4; i += WGT) dst[i] = src[i];
+    }
+    __syncthreads();
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, p.NC, true, accum};
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bid = (int)blockIdx.x;
+    const unsigned *ord = p.order;
+    if (p.nframes > 1) {
+        const int frame = bid / p.bpf;
+        bid -= frame * p.bpf;
+        if (ord && frame < p.nframes - 1) ord += p.seq_offset;
+    }
+    const int block = ord ? (int)ord[bid] : bid;
+    const int tile = block * WPW + wave;                                      // (a wave without a tile idles through the barriers)
+    const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
+    const int x = p.x0 + tx * TILE + (lane >> 3);
+    const int y = ty * TILE + (lane & 7);
+    bool inb = (tile < p.ntiles) && (x < p.x1) && (y < p.h);
+    if constexpr (LAT) inb = inb && ((((x | y) & 1) == 0) || (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2));
+    const int xc = inb ? x : p.x0, yc = inb ? y : 0;
+
+    volatile lds_f64 *accp = (volatile lds_f64 *)accum;                       // colour of the ray with slot s: accp[c WGT + s]
+    volatile lds_f64 *xb = (volatile lds_f64 *)accum + 3 * WGT;               // exchange buffer (= trace_bounce's parked direction)
+    typedef __attribute__((address_space(3))) int lds_i32;
+    volatile lds_i32 *xs = (volatile lds_i32 *)xslot;
+    const V3 cam{p.cam_o[0], p.cam_o[1], p.cam_o[2]};
+    RayCount<false> cnt;
+    const bool stoch = AA && (p.aa == 2);
+    const bool interior = AA && !stoch && inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
+    // (every wave of the workgroup must run the same number of taps: the tap loop holds barriers)
+    int any_interior = 0;
+    if constexpr (AA) {
+        if (lane == 0) pool[wave] = (__builtin_amdgcn_ballot_w64(interior) != 0ull) ? 1u : 0u;
+        __syncthreads();
+        for (int w = 0; w < WPW; ++w) any_interior |= (int)pool[w];
+        any_interior = __builtin_amdgcn_readfirstlane(any_interior);
+        __syncthreads();
+    }
+    const int ntaps = !AA ? 1 : (stoch ? p.spp : (any_interior ? 9 : 1));
+    constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;                          // kernels.py:53 (see render_kernel)
+    Park3<AA, WGT> taps(lds.acc, 2);
+#pragma unroll 1
+    for (int tap = 0; tap < ntaps; ++tap) {
+        V3 Pt;
+        if constexpr (LAT) Pt = lattice_P(p, xc, yc);
+        else {
+            const V3 Pp = pixel_P(p, xc, yc);                                 // kernels.py:19
+            Pt = Pp;
+            if (stoch) {
+                const unsigned hh = jitter_hash((unsigned)xc, (unsigned)yc, (unsigned)tap, p.seed);
+                const double u = (double)(hh & 0xFFFFu) * 0x1p-16 + (0x1p-17 - 0.5);
+                const double v = (double)(hh >> 16) * 0x1p-16 + (0x1p-17 - 0.5);
+                Pt = V3{Pp.x, Pp.y + u * p.dy, Pp.z + v * p.dz};
+            } else if (AA && tap) {
+                const int k = tap - 1;
+                const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
+                const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
+                Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // kernels.py:43-50
+            }
+        }
+        const bool mine = (AA && tap && !stoch) ? interior : inb;             // this thread's pixel takes part in this sample
+        V3 o = cam, d = primary_dir(p, Pt);                                   // kernels.py:16, :22-23
+        bool alive = mine;
+        int slot = (int)threadIdx.x;
+        int holding = WPW;                                                    // waves [0, holding) hold the workgroup's rays
+        for (int b = 0; b <= p.depth; ++b) {                                  // trace.py:120-131, one bounce for the whole pool
+            const unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
+            volatile unsigned *cntw = pool + (b & 1) * WPW;
+            if (lane == 0) cntw[wave] = (unsigned)__builtin_popcountll(am);
+            __syncthreads();
+            int n = 0, base = 0;
+#pragma unroll
+            for (int w = 0; w < WPW; ++w) { const int c = (int)cntw[w]; base += w < wave ? c : 0; n += c; }
+            n = __builtin_amdgcn_readfirstlane(n); base = __builtin_amdgcn_readfirstlane(base);
+            if (n == 0) break;                                                // the same for every wave of the workgroup
+            const int need = (n + 63) >> 6;
+            if (need < holding && p.pool_repack) {                            // the live rays fit fewer waves: re-pack them
+                const int dest = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                const bool has = (int)threadIdx.x < n;
+                if (alive) { xb[dest] = o.x; xb[WGT + dest] = o.y; xb[2 * WGT + dest] = o.z; xs[dest] = slot; }
+                __syncthreads();
+                if (has) { o = V3{xb[threadIdx.x], xb[WGT + threadIdx.x], xb[2 * WGT + threadIdx.x]}; slot = xs[threadIdx.x]; }
+                __syncthreads();
+                if (alive) { xb[dest] = d.x; xb[WGT + dest] = d.y; xb[2 * WGT + dest] = d.z; }
+                __syncthreads();
+                if (has) d = V3{xb[threadIdx.x], xb[WGT + threadIdx.x], xb[2 * WGT + threadIdx.x]};
+                __syncthreads();                                              // (trace_bounce parks directions in the same buffer)
+                alive = has;
+                holding = need;
+            }
+            const bool was = alive;
+            V3 rgb{0.0, 0.0, 0.0};
+            if (wave < holding)                                               // wave-uniform
+                trace_bounce<true, WGT, false, true>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
+            if (was) {                                                        // :120 / :131 (a bounce that missed adds pow * 0)
+                if (b == 0) { accp[slot] = rgb.x; accp[WGT + slot] = rgb.y; accp[2 * WGT + slot] = rgb.z; }
+                else {
+                    const double wgt = p.refl_pow[b - 1];
+                    accp[slot] = accp[slot] + wgt * rgb.x;
+                    accp[WGT + slot] = accp[WGT + slot] + wgt * rgb.y;
+                    accp[2 * WGT + slot] = accp[2 * WGT + slot] + wgt * rgb.z;
+                }
+            }
+        }
+        __syncthreads();                                                      // every path of the sample has ended: the colours are complete
+        if constexpr (AA) {
+            const V3 sC{accp[threadIdx.x], accp[WGT + threadIdx.x], accp[2 * WGT + threadIdx.x]};
+            if (tap == 0) taps.set(sC);
+            else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + sC.x, a.y + sC.y, a.z + sC.z}); }
+            else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + sC.x, a.y + sC.z, a.z + sC.y}); }   // kernels.py:58-60 (G += B_s; B += G_s)
+            __syncthreads();                                                  // the next sample reuses the colour slots
+        }
+    }
+    double R, G, B;
+    if constexpr (AA) {
+        const V3 a = taps.get(); R = a.x; G = a.y; B = a.z;
+        if (stoch) { const double nn = (double)p.spp; R = R / nn; G = G / nn; B = B / nn; }
+        else if (interior) { R = R / 9; G = G / 9; B = B / 9; }               // kernels.py:63-65
+    } else { R = accp[threadIdx.x]; G = accp[WGT + threadIdx.x]; B = accp[2 * WGT + threadIdx.x]; }
+    if (inb) {
+        const long long off = (long long)(x - p.x0) * p.h + y;
+        if constexpr (LAT) {
+            double *q = p.out_f64 + off * 3;
+            q[0] = R; q[1] = G; q[2] = B;
+        } else {
+            const long long fo = opaque(p.nframes) > 1 ? (long long)((int)blockIdx.x / p.bpf) * p.frame_stride : 0ll;
+            store_pixel(p, off, fo, R, G, B);
+        }
+    }
+    if ((p.tile_cycles || p.cost) && lane == 0) {                             // timing only; never feeds a pixel
+        const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+        if (p.tile_cycles && tile < p.ntiles) p.tile_cycles[tile] = cyc;
+        if (p.cost) {
+            atomicAdd(&wgstat[0], cyc >> 2);
+            if ((int)atomicAdd(&wgstat[1], 1u) == WPW - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
         }
     }
 }
