@@ -87,7 +87,14 @@ struct KParams {
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs (XCD-affine, longest
                                // first inside every XCD); order + bpf: the same XCD assignment in plain tile order, which all but the
                                // last frame of a multi-frame launch use (order_kernel)
-    int pool_repack;           // render_pool_kernel: 0 = never re-pack (A/B: the cost of the lockstep alone)
+    // Wavefront path of the large clustered scenes (wf_primary_kernel / wf_level_kernel / wf_resolve_kernel):
+    double *wf_in, *wf_out;    // ray queues, structure of arrays: component c (o.xyz, d.xyz, colour.xyz) of ray i at q[c * wf_cap + i]
+    int *wf_pix_in, *wf_pix_out;   // the pixel (offset within the launch's slab) each queued ray belongs to
+    unsigned *wf_cnt;          // [l] rays queued for bounce l; [32 + l] chunks of bounce l handed out so far (zeroed per sample pass)
+    double *wf_acc;            // finished paths: float64 (R,G,B) per pixel, [pixel][3]
+    double *wf_taps;           // AA modes: the running sum over the samples of a pixel
+    long long wf_cap;
+    int wf_level, wf_split, wf_tap, wf_ntaps;
     int seq_offset;            // bpf, or 0 to dispatch every frame of a multi-frame launch longest-first (MI355RT_SEQ_ORDER=0)
     int nframes, bpf;          // frames rendered by this launch (rt_render_sequence) and workgroups per frame: workgroup b renders
                                // block order[b % bpf] of frame b / bpf into the outputs + (b / bpf) * frame_stride elements
@@ -605,14 +612,37 @@ __device__ __forceinline__ void plane_den_num(const double *__restrict__ g, int 
     }
 }
 
-// intersections.py:6-38 for one sphere record g (float64), on the quadratic divided by 4 (see above), feeding the
-// closest-hit selection: bestn = numerator of the current winner, bidx its slot, borig its caller's index.
-__device__ __forceinline__ void sphere_closest(const double *g, int k, const V3 &o, const V3 &R, double a,
-                                               double &bestn, int &bidx, double &borig)
+// What a sphere test reads of sphere slot k: centre and r*r.  F32 (the kernels of the large clustered scenes, MODE 2): from
+// the float32 table the cull already keeps in LDS, widened on use — the scene IS float32 (scene.py:18) and r*r is a float32
+// product (intersections.py:21), so the widening is exact; those kernels stage no float64 sphere records at all (config 5:
+// 16 KB of LDS, which is what lets their long-lived state be parked in LDS instead of spilling to scratch), and read a hit
+// sphere's colour and caller's index from the packed scene in global memory, at the point of use.
+struct SphHot { double x, y, z, r2; };
+template <bool F32> __device__ __forceinline__ SphHot sphere_hot(const Lds &lds, int k)
 {
-    const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};         // :16
+    if constexpr (F32) {
+        const f4 c = *(lds_cf4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const float *)(lds.sph32 + 4 * k);
+        return SphHot{(double)c[0], (double)c[1], (double)c[2], (double)c[3]};
+    } else {
+        const double *g = lds.recs() + k * SPH_STRIDE;
+        return SphHot{g[0], g[1], g[2], g[3]};
+    }
+}
+template <bool F32> __device__ __forceinline__ double sphere_orig(const Lds &lds, const KParams &p, int k)   // the caller's index of slot k
+{
+    if constexpr (F32) return p.scene[(size_t)k * SPH_STRIDE + 7]; else return lds.recs()[k * SPH_STRIDE + 7];
+}
+
+// intersections.py:6-38 for the sphere in slot k (float64), on the quadratic divided by 4 (see above), feeding the
+// closest-hit selection: bestn = numerator of the current winner, bidx its slot.
+template <bool F32>
+__device__ __forceinline__ void sphere_closest(const Lds &lds, const KParams &p, int k, const V3 &o, const V3 &R, double a,
+                                               double &bestn, int &bidx)
+{
+    const SphHot g = sphere_hot<F32>(lds, k);
+    const V3 Lv{o.x - g.x, o.y - g.y, o.z - g.z};            // :16
     const double s = dot3(Lv, R);                             // b/2
-    const double cc = dot3(Lv, Lv) - g[3];                    // :21 (g[3] = float32 r*r, widened)
+    const double cc = dot3(Lv, Lv) - g.r2;                    // :21 (r2 = float32 r*r, widened)
     const double D = s * s - a * cc;                          // disc/4
     if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
         const double q = __builtin_sqrt(D);
@@ -625,27 +655,30 @@ __device__ __forceinline__ void sphere_closest(const double *g, int k, const V3 
         // decides.  Numerators further apart than a relative 2^-50 have different quotients in the same
         // order (the gap is four ulp); for closer ones (equal included) both quotients are formed and the
         // reference's rule is applied literally.  Wave-uniform branch, practically never taken.
-        // Slots are visited in any order (clustered scenes permute them): g[7] is the caller's index.
+        // Slots are visited in any order (clustered scenes permute them): the records keep the caller's index, which is
+        // looked up only here, for the two spheres of a tie.
         if (n > 0.0) {
             bool take = n < bestn;
-            const bool close = __builtin_fabs(n - bestn) < bestn * 0x1p-50;   // false while bestn = +inf
+            const bool close = __builtin_fabs(n - bestn) < bestn * 0x1p-50;   // false while bestn = +inf (bidx = -1)
             if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
                 if (close) {
                     const double tq = n / a, tb = bestn / a;                  // :31 / :36
-                    take = tq < tb || (tq == tb && g[7] < borig);
+                    take = tq < tb || (tq == tb && sphere_orig<F32>(lds, p, k) < sphere_orig<F32>(lds, p, bidx));
                 }
             }
-            if (take) { bestn = n; bidx = k; borig = g[7]; }
+            if (take) { bestn = n; bidx = k; }
         }
     }
 }
 
 // the same sphere for a shadow (any-hit) query: does it report 0 < t < 999?
-__device__ __forceinline__ bool sphere_any(const double *g, const V3 &o, const V3 &R, double a, bool a_sane)
+template <bool F32>
+__device__ __forceinline__ bool sphere_any(const Lds &lds, int k, const V3 &o, const V3 &R, double a, bool a_sane)
 {
-    const V3 Lv{o.x - g[0], o.y - g[1], o.z - g[2]};
+    const SphHot g = sphere_hot<F32>(lds, k);
+    const V3 Lv{o.x - g.x, o.y - g.y, o.z - g.z};
     const double s = dot3(Lv, R);
-    const double cc = dot3(Lv, Lv) - g[3];
+    const double cc = dot3(Lv, Lv) - g.r2;
     const double D = s * s - a * cc;
     if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
         // s < 0: the larger numerator n2 = -s + q is positive, so a positive root exists and
@@ -766,7 +799,7 @@ __device__ __forceinline__ void lane_stats(const KParams &p, int base, unsigned 
 #endif
 template <bool ANCH>
 __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, int anchor, const V3 &o, const V3 &R, double a,
-                                              double &bestn, int &bidx, double &borig)
+                                              double &bestn, int &bidx)
 {
     RayF q = make_rayf_dir(R);
     if constexpr (!ANCH) add_origin(q, o, p.extent2);
@@ -791,7 +824,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
                     if (sm != 0u) {
                         const int k = kb + __builtin_ctz(sm);
                         sm &= sm - 1u;
-                        sphere_closest(lds.recs() + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
+                        sphere_closest<true>(lds, p, k, o, R, a, bestn, bidx);
                     }
                 }
             }
@@ -841,7 +874,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
                     if (sm != 0u) {
                         const int k = kb + __builtin_ctz(sm);
                         sm &= sm - 1u;
-                        if (sphere_any(lds.recs() + k * SPH_STRIDE, o, R, a, a_sane)) { occ = true; sm = 0u; cm = 0u; }
+                        if (sphere_any<true>(lds, k, o, R, a, a_sane)) { occ = true; sm = 0u; cm = 0u; }
                     }
                 }
             }
@@ -867,13 +900,14 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #if RT_PREFILTER
     const int canchor = (opaque(p.anchors) > 0) ? anchor : -1;
 #endif
-    double bestn = __builtin_inf(), borig = 0.0;
+    double bestn = __builtin_inf();
     int bidx = -1;
+    constexpr bool F32 = MODE >= 2;                           // sphere records: the float32 LDS table (see sphere_hot)
     // lane-owned traversal for the rays without a common anchor (bounce 1 on), where the wave's rays have parted;
     // the primary rays of a tile travel together: the wave-uniform cull below is cheaper for them
     if (MODE >= 2 && lds.NC > 0 && (canchor < 0 || p.lanes_primary)) {
-        if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx, borig);
-        else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx, borig);
+        if (canchor >= 0) lanes_closest<true>(lds, p, canchor, o, R, a, bestn, bidx);
+        else lanes_closest<false>(lds, p, -1, o, R, a, bestn, bidx);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
       const int n = (S - k0 < 64) ? S - k0 : 64;
@@ -888,7 +922,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
       while (mask) {                                          // spheres some live lane might hit, ascending
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        sphere_closest(lds.recs() + k * SPH_STRIDE, k, o, R, a, bestn, bidx, borig);
+        sphere_closest<F32>(lds, p, k, o, R, a, bestn, bidx);
       }
     }
     double best = 999.0;                                      // trace.py:17
@@ -897,7 +931,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
         const double t = bestn / a;                           // :31 / :36, once per query
         if (best > t && t > 0.0) { best = t; idx = bidx; type = HIT_SPHERE; }
     }
-    const double *pl = lds.recs() + opaque(p.S) * SPH_STRIDE;
+    const double *pl = lds.recs() + (F32 ? 0 : opaque(p.S) * SPH_STRIDE);
     for (int k = 0; k < P; ++k) {                             // intersections.py:41-68
         const double *g = pl + k * PL_STRIDE;
         double den, num;
@@ -949,10 +983,10 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        if (!occ) occ = sphere_any(lds.recs() + k * SPH_STRIDE, o, R, a, a_sane);
+        if (!occ) occ = sphere_any<(MODE >= 2)>(lds, k, o, R, a, a_sane);
       }
     }
-    const double *pl = lds.recs() + opaque(p.S) * SPH_STRIDE;
+    const double *pl = lds.recs() + (MODE >= 2 ? 0 : opaque(p.S) * SPH_STRIDE);
     for (int k = 0; k < P; ++k) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         if (!occ) {
@@ -1005,18 +1039,26 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         V3 Pt{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                   // :60 (1.0*o is exact)
         // PARK: the object's colour is re-read from its LDS record where it is used (volatile: at the point of
         // use) instead of being held in 6 VGPRs across the shadow queries
-        const int coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : opaque(S) * SPH_STRIDE + idx * PL_STRIDE + 12;
+        // LANES kernels keep no float64 sphere records in LDS (sphere_hot): the planes' and lights' records start at 0, and a
+        // hit sphere's colour comes from the packed scene in global memory — through one flat pointer that serves both cases
+        const int plb = LANES ? 0 : opaque(S) * SPH_STRIDE;
+        const int coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : plb + idx * PL_STRIDE + 12;
         volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.recs() + coff;
+        volatile const double *colf = (LANES && type == HIT_SPHERE) ? p.scene + coff : lds.recs() + coff;
         V3 colr{0.0, 0.0, 0.0};
-        if constexpr (!PARK) colr = V3{lds.recs()[coff], lds.recs()[coff + 1], lds.recs()[coff + 2]};
-        auto col = [&](int c) -> double { if constexpr (PARK) return colp[c]; else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z); };
+        if constexpr (!PARK) colr = V3{colf[0], colf[1], colf[2]};
+        auto col = [&](int c) -> double {
+            if constexpr (PARK && LANES) return colf[c];
+            else if constexpr (PARK) return colp[c];
+            else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z);
+        };
         V3 N, bN;
         if (type == HIT_SPHERE) {                                             // :63-66
-            const double *g = lds.recs() + idx * SPH_STRIDE;
-            N = normalize3(V3{Pt.x - g[0], Pt.y - g[1], Pt.z - g[2]});        // common.py:94-101
+            const SphHot g = sphere_hot<LANES>(lds, idx);
+            N = normalize3(V3{Pt.x - g.x, Pt.y - g.y, Pt.z - g.z});           // common.py:94-101
             bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
         } else {                                                              // :68-71
-            const double *g = lds.recs() + opaque(S) * SPH_STRIDE + idx * PL_STRIDE;
+            const double *g = lds.recs() + plb + idx * PL_STRIDE;
             N = V3{g[6], g[7], g[8]};                                         // float32-renormalised, host-side
             bN = V3{g[9], g[10], g[11]};                                      // BIAS*N as the reference rounds it
         }
@@ -1026,7 +1068,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         Park3<PARK, WGT> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
         dpark.set(d);
 
-        const double *lt = lds.recs() + opaque(S) * SPH_STRIDE + opaque(P) * PL_STRIDE;
+        const double *lt = lds.recs() + plb + opaque(P) * PL_STRIDE;
         for (int m = 0; m < L; ++m) {                                         // :86-102
             const double *g = lt + m * LT_STRIDE;
             const V3 Ld = normalize3(V3{g[0] - Pt.x, g[1] - Pt.y, g[2] - Pt.z});   // common.py:84-91
@@ -1156,7 +1198,7 @@ __device__ __forceinline__ void store_pixel(const KParams &p, long long off, lon
 
 // LDS image: [float64 records][per-thread slots 6|9 x 256 doubles][256 int32 pixel offsets][float32 sphere table S x 4][cull table anchors x S x CULL_STRIDE]
 __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (size_t)S * SPH_STRIDE + (size_t)P * PL_STRIDE + (size_t)L * LT_STRIDE; }
-__host__ __device__ inline int lds_slots(bool aa, bool park) { return park ? (aa ? 9 : 6) : 0; }   // x workgroup-size doubles
+__host__ __device__ inline int lds_slots(bool aa, bool park, bool mode2 = false) { return park ? ((aa && !mode2) ? 9 : 6) : 0; }   // x workgroup-size doubles (MODE 2: the tap sums stay in registers)
 __host__ __device__ inline int lds_offset_words(bool park, int wgt) { return park ? wgt : 0; }    // + one int32 per thread: the pixel offset
 // The float32 tables of a scene, offsets in floats (every one a multiple of 4):
 //   sph32 | anchored table | cluster anchored table | cluster boxes | group boxes | group anchored table | cluster sph32
@@ -1183,9 +1225,10 @@ __host__ __device__ inline size_t table_floats(int S, int NC, int anchors, bool 
     const TableLayout t = table_layout(S, NC, anchors);
     return lanes ? t.total_lanes : t.total;
 }
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool lanes = false)
+// mode2: the kernels of the large clustered scenes (lane-owned traversal) stage no float64 sphere records (sphere_hot)
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool lanes = false, bool mode2 = false)
 {
-    return (lds_doubles(S, P, L) + (size_t)lds_slots(aa, park) * wgt) * sizeof(double) +
+    return (lds_doubles(mode2 ? 0 : S, P, L) + (size_t)lds_slots(aa, park, mode2) * wgt) * sizeof(double) +
            ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16;   // + workgroup cost/arrival words
 }
 
@@ -1308,9 +1351,11 @@ template <bool AA, bool PARK, int WPW, bool COUNT = false, bool LAT = false, int
 __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT_W_AAPARK : 4) : (PARK ? RT_W_PARK : 5))) void render_kernel(const KParams p)
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
-    const int nrec = (int)lds_doubles(p.S, p.P, p.L);
+    constexpr bool M2 = MODE >= 2;
+    const int nrec = (int)lds_doubles(M2 ? 0 : p.S, p.P, p.L);                // MODE 2: planes and lights only (sphere_hot)
+    const double *rec_src = p.scene + (M2 ? (size_t)p.S * SPH_STRIDE : 0);
     double *accum = lds_raw + nrec;
-    int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK) * WG_THREADS);
+    int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK, M2) * WG_THREADS);
     float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK, WG_THREADS));
     const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
     // the lane-owned kernels leave the clusters' origin-form spheres in global memory: with anchored tables in place the only
@@ -1324,7 +1369,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
         // used to be computed here, by every workgroup: 3 % of the frame's VALU instructions and a second barrier.)
-        for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = p.scene[i];
+        for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = rec_src[i];
 #if RT_PREFILTER
         const int nf4 = (int)((LANES ? tl.total_lanes : tl.total) / 4);
         const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
@@ -1387,7 +1432,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
         // neighbour offsets (dx,dy)+1 packed 2 bits each, in the order of kernels.py:53:
         // left, right, top(y+1), bottom(y-1), top-left, top-right, bottom-left, bottom-right
         constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;
-        Park3<PARK, WG_THREADS> taps(lds.acc, 2);
+        Park3<PARK && !M2, WG_THREADS> taps(lds.acc, 2);
 #pragma unroll 1
         for (int tap = 0; tap < ntaps; ++tap) {
             const V3 Pp = pixel_P(p, xc, yc);                                 // :19
@@ -1447,191 +1492,186 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
 }
 
 // ---------------------------------------------------------------------------------------------
-// The kernel of the large clustered scenes (lane-owned traversal, MODE 2; from 161 spheres on): workgroups of WPW = 8
-// wavefronts that RE-PACK their surviving rays between bounces.
+// Wavefront path of the large clustered scenes (lane-owned traversal, MODE 2; from 161 spheres on).
 //
-// A ray path ends when a bounce misses (trace.py:124-126), so after a few bounces a tile's wave runs with a fraction of its
-// lanes: measured on config 5 (round 2, one wave per tile for the whole path), the lanes alive per bounce were 1.00, 1.00,
-// 0.95, 0.85, 0.72, 0.57, 0.44, 0.34, 0.26 of the wave, and bounces 2-8 took 55 % of the frame for 25 % of its queries.
-// Here the 512 rays of a workgroup's eight tiles are a POOL: before every bounce the workgroup counts its live rays and,
-// when they fit fewer wavefronts than currently hold them, copies (origin, direction, slot) of every live ray through LDS
-// to the lowest lanes of the workgroup — order preserving, so neighbours stay neighbours — and the wavefronts left without
-// a ray sit the bounce out.  A ray's colour does not travel: it is accumulated in LDS under the ray's SLOT (the thread that
-// generated it, which owns the pixel and stores it at the end), in the reference's order — RGB += refl**(i+1) RGB_i is
-// sequential per path (trace.py:131), and every bounce is the same bounce for all rays of the workgroup, so the weight and
-// the cull anchor stay wave-uniform.  The same float64 operations on the same values: frames are bit-identical.
-// Eight waves per workgroup instead of four: the scene image (config 5: 40 KB) is staged once for twice as many rays, which
-// is what makes room for the colour slots, the exchange buffer and the parked direction (no scratch), at the same 16 waves
-// per CU.  Barriers: one per bounce for the count, four per re-pack (two passes of three doubles through one 12 KB buffer,
-// which is also where trace_bounce parks the incoming direction).
+// A path ends when a bounce misses (trace.py:124-126).  With one wave per 8x8 tile for the whole path (round 2), config 5's
+// waves ran bounces 2..8 with 0.95, 0.85, 0.72, 0.57, 0.44, 0.34, 0.26 of their lanes, and — worse — the few waves that
+// still had a live path kept their workgroup's slot while its other waves had finished: bounce 8 cost 0.6 ms for 1.5 million
+// rays where bounce 0 cost 2.4 ms for 33 million primary and 80 million shadow rays (profiles/r02_c5/depth_sweep.txt).
+// Here the frame is rendered bounce by bounce over QUEUES of live rays in HBM (sized for the whole frame: 288 GB are there
+// to be used):
+//   wf_primary_kernel   one wave per tile as before: ray generation and the first wf_split bounces (0 and 1, where every
+//                       lane has a path); a path that is still alive is appended to the queue of bounce wf_split —
+//                       origin, direction, colour so far, pixel — and a path that has ended leaves its colour in wf_acc;
+//   wf_level_kernel     one launch per later bounce, persistent workgroups (the scene image is staged ONCE per workgroup):
+//                       every wave takes chunks of 64 consecutive queued rays — all lanes live — traces the bounce, adds
+//                       refl**l times its colour (trace.py:131: the sum is sequential per path, and a path's bounces run in
+//                       consecutive launches), and appends the survivors, compacted by a ballot and ONE atomic per wave, to
+//                       the next bounce's queue;
+//   wf_resolve_kernel   clips and stores the pixels (kernels.py:69-73), or — anti-aliasing modes — folds the sample into the
+//                       pixel's running sum in the reference's order (one pass of the three kernels per sample).
+// The same float64 operations on the same values in the same order per path: frames are bit-identical.  Queue traffic:
+// 76 bytes per live ray and bounce, written once and read once, coalesced (structure of arrays).
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t lds_pool_bytes(int S, int P, int L, int NC, int anchors, bool aa, int wgt)
+constexpr int WF_COMP = 9;                   // doubles per queued ray
+constexpr int WF_THREADS = 256;
+
+// the survivors of a wave -> consecutive entries of the next queue (one atomic per wave)
+__device__ __forceinline__ void wf_append(const KParams &p, bool go, const V3 &o, const V3 &d, const V3 &c, int pix, int level)
 {
-    return (lds_doubles(S, P, L) + (size_t)(aa ? 9 : 6) * wgt) * sizeof(double) + (size_t)wgt * sizeof(int) +
-           table_floats(S, NC, anchors, anchors > 0) * sizeof(float) + 16 + (size_t)(2 * (wgt / 64) + 4) * sizeof(unsigned);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(go);
+    if (m == 0ull) return;                                                    // wave-uniform
+    unsigned base = 0;
+    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&p.wf_cnt[level], (unsigned)__builtin_popcountll(m));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    if (go) {
+        const long long i = (long long)base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        double *q = p.wf_out + i;
+        q[0] = o.x; q[p.wf_cap] = o.y; q[2 * p.wf_cap] = o.z;
+        q[3 * p.wf_cap] = d.x; q[4 * p.wf_cap] = d.y; q[5 * p.wf_cap] = d.z;
+        q[6 * p.wf_cap] = c.x; q[7 * p.wf_cap] = c.y; q[8 * p.wf_cap] = c.z;
+        p.wf_pix_out[i] = pix;
+    }
 }
 
-template <bool AA, bool LAT, int WPW>
-__global__ __launch_bounds__(64 * WPW, RT_W_LANES) void render_pool_kernel(const KParams p)
+// stages the MODE 2 LDS image (planes' and lights' records + the float32 tables) and returns the table pointers
+__device__ __forceinline__ Lds wf_stage(const KParams &p, int wg_threads)
 {
-    constexpr int WGT = 64 * WPW;
-    const int nrec = (int)lds_doubles(p.S, p.P, p.L);
-    double *accum = lds_raw + nrec;                    // [0, 3 WGT) colour by ray slot | [3 WGT, 6 WGT) parked direction / exchange | AA: [6 WGT, 9 WGT) tap sums
-    int *xslot = reinterpret_cast<int *>(accum + (AA ? 9 : 6) * WGT);
-    float *sph32 = reinterpret_cast<float *>(xslot + WGT);
+    const int nrec = (int)lds_doubles(0, p.P, p.L);
+    const double *rec_src = p.scene + (size_t)p.S * SPH_STRIDE;
+    float *sph32 = reinterpret_cast<float *>(lds_raw + nrec);
     const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
-    const bool LANES = p.anchors > 0;                  // (as in render_kernel: with anchored tables the clusters' origin-form spheres stay in global memory)
-    float *tab = sph32 + tl.tab;
-    float *csph32 = LANES ? nullptr : sph32 + tl.csph32;
-    float *ctab = sph32 + tl.ctab;
-    float *cbox = sph32 + tl.cbox;
-    unsigned *wgstat = reinterpret_cast<unsigned *>(sph32 + (LANES ? tl.total_lanes : tl.total));   // {cycles, waves done, -, -}
-    volatile unsigned *pool = wgstat + 4;              // live rays per wave, two sets (bounce parity)
-    if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
-    {
-        for (int i = threadIdx.x; i < nrec; i += WGT) lds_raw[i] = p.scene[i];
-        const int nf4 = (int)((LANES ? tl.total_lanes : tl.total) / 4);
-        const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
-        f4 *dst = reinterpret_cast<f4 *>(sph32);
-        for (int i = threadIdx.x; i < nf4; i += WGT) dst[i] = src[i];
-    }
+    const bool ltab = p.anchors > 0;
+    for (int i = threadIdx.x; i < nrec; i += wg_threads) lds_raw[i] = rec_src[i];
+    const int nf4 = (int)((ltab ? tl.total_lanes : tl.total) / 4);
+    const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
+    f4 *dst = reinterpret_cast<f4 *>(sph32);
+    for (int i = threadIdx.x; i < nf4; i += wg_threads) dst[i] = src[i];
     __syncthreads();
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, p.NC, true, accum};
+    return Lds{sph32, sph32 + tl.tab, ltab ? nullptr : sph32 + tl.csph32, sph32 + tl.ctab, sph32 + tl.cbox, sph32 + tl.gbox, sph32 + tl.gtab,
+               p.NC, true, nullptr};
+}
 
+template <bool LAT>
+__global__ __launch_bounds__(WF_THREADS, RT_W_LANES) void wf_primary_kernel(const KParams p)
+{
+    constexpr int WPW = WF_THREADS / 64;
+    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
+    unsigned *wgstat = reinterpret_cast<unsigned *>(reinterpret_cast<float *>(lds_raw + lds_doubles(0, p.P, p.L)) + (p.anchors > 0 ? tl.total_lanes : tl.total));
+    if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
+    const Lds lds = wf_stage(p, WF_THREADS);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int bid = (int)blockIdx.x;
-    const unsigned *ord = p.order;
-    if (p.nframes > 1) {
-        const int frame = bid / p.bpf;
-        bid -= frame * p.bpf;
-        if (ord && frame < p.nframes - 1) ord += p.seq_offset;
-    }
-    const int block = ord ? (int)ord[bid] : bid;
-    const int tile = block * WPW + wave;                                      // (a wave without a tile idles through the barriers)
+    const int block = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;
+    const int tile = block * WPW + wave;
+    if (tile >= p.ntiles) return;                                             // whole wave, after the barrier
     const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
     const int x = p.x0 + tx * TILE + (lane >> 3);
     const int y = ty * TILE + (lane & 7);
-    bool inb = (tile < p.ntiles) && (x < p.x1) && (y < p.h);
+    bool inb = (x < p.x1) && (y < p.h);
     if constexpr (LAT) inb = inb && ((((x | y) & 1) == 0) || (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2));
     const int xc = inb ? x : p.x0, yc = inb ? y : 0;
-
-    volatile lds_f64 *accp = (volatile lds_f64 *)accum;                       // colour of the ray with slot s: accp[c WGT + s]
-    volatile lds_f64 *xb = (volatile lds_f64 *)accum + 3 * WGT;               // exchange buffer (= trace_bounce's parked direction)
-    typedef __attribute__((address_space(3))) int lds_i32;
-    volatile lds_i32 *xs = (volatile lds_i32 *)xslot;
-    const V3 cam{p.cam_o[0], p.cam_o[1], p.cam_o[2]};
+    const int pix = (x - p.x0) * p.h + y;
+    // the sample of this pass (wf_tap): as render_kernel generates it
+    V3 Pt;
+    bool mine = inb;
+    if constexpr (LAT) Pt = lattice_P(p, xc, yc);
+    else {
+        const V3 Pp = pixel_P(p, xc, yc);                                     // kernels.py:19
+        Pt = Pp;
+        if (p.aa == 2) {
+            const unsigned hh = jitter_hash((unsigned)xc, (unsigned)yc, (unsigned)p.wf_tap, p.seed);
+            const double u = (double)(hh & 0xFFFFu) * 0x1p-16 + (0x1p-17 - 0.5);
+            const double v = (double)(hh >> 16) * 0x1p-16 + (0x1p-17 - 0.5);
+            Pt = V3{Pp.x, Pp.y + u * p.dy, Pp.z + v * p.dz};
+        } else if (p.aa == 1 && p.wf_tap) {
+            constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;                  // kernels.py:53 (see render_kernel)
+            const bool interior = inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
+            const int k = p.wf_tap - 1;
+            const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
+            const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
+            Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // kernels.py:43-50
+            mine = interior;
+        }
+    }
+    V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]}, d = primary_dir(p, Pt);         // kernels.py:16, :22-23
+    bool alive = mine;
+    V3 acc{0.0, 0.0, 0.0};
     RayCount<false> cnt;
-    const bool stoch = AA && (p.aa == 2);
-    const bool interior = AA && !stoch && inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
-    // (every wave of the workgroup must run the same number of taps: the tap loop holds barriers)
-    int any_interior = 0;
-    if constexpr (AA) {
-        if (lane == 0) pool[wave] = (__builtin_amdgcn_ballot_w64(interior) != 0ull) ? 1u : 0u;
-        __syncthreads();
-        for (int w = 0; w < WPW; ++w) any_interior |= (int)pool[w];
-        any_interior = __builtin_amdgcn_readfirstlane(any_interior);
-        __syncthreads();
+    const int last = p.depth < p.wf_split - 1 ? p.depth : p.wf_split - 1;
+    for (int b = 0; b <= last; ++b) {                                         // trace.py:120-131, the first bounces
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+        V3 rgb;
+        trace_bounce<false, WF_THREADS, false, true>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
+        if (b == 0) acc = rgb;
+        else { const double wgt = p.refl_pow[b - 1]; acc = V3{acc.x + wgt * rgb.x, acc.y + wgt * rgb.y, acc.z + wgt * rgb.z}; }
     }
-    const int ntaps = !AA ? 1 : (stoch ? p.spp : (any_interior ? 9 : 1));
-    constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;                          // kernels.py:53 (see render_kernel)
-    Park3<AA, WGT> taps(lds.acc, 2);
-#pragma unroll 1
-    for (int tap = 0; tap < ntaps; ++tap) {
-        V3 Pt;
-        if constexpr (LAT) Pt = lattice_P(p, xc, yc);
-        else {
-            const V3 Pp = pixel_P(p, xc, yc);                                 // kernels.py:19
-            Pt = Pp;
-            if (stoch) {
-                const unsigned hh = jitter_hash((unsigned)xc, (unsigned)yc, (unsigned)tap, p.seed);
-                const double u = (double)(hh & 0xFFFFu) * 0x1p-16 + (0x1p-17 - 0.5);
-                const double v = (double)(hh >> 16) * 0x1p-16 + (0x1p-17 - 0.5);
-                Pt = V3{Pp.x, Pp.y + u * p.dy, Pp.z + v * p.dz};
-            } else if (AA && tap) {
-                const int k = tap - 1;
-                const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
-                const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
-                Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // kernels.py:43-50
-            }
-        }
-        const bool mine = (AA && tap && !stoch) ? interior : inb;             // this thread's pixel takes part in this sample
-        V3 o = cam, d = primary_dir(p, Pt);                                   // kernels.py:16, :22-23
-        bool alive = mine;
-        int slot = (int)threadIdx.x;
-        int holding = WPW;                                                    // waves [0, holding) hold the workgroup's rays
-        for (int b = 0; b <= p.depth; ++b) {                                  // trace.py:120-131, one bounce for the whole pool
-            const unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
-            volatile unsigned *cntw = pool + (b & 1) * WPW;
-            if (lane == 0) cntw[wave] = (unsigned)__builtin_popcountll(am);
-            __syncthreads();
-            int n = 0, base = 0;
-#pragma unroll
-            for (int w = 0; w < WPW; ++w) { const int c = (int)cntw[w]; base += w < wave ? c : 0; n += c; }
-            n = __builtin_amdgcn_readfirstlane(n); base = __builtin_amdgcn_readfirstlane(base);
-            if (n == 0) break;                                                // the same for every wave of the workgroup
-            const int need = (n + 63) >> 6;
-            if (need < holding && p.pool_repack) {                            // the live rays fit fewer waves: re-pack them
-                const int dest = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
-                const bool has = (int)threadIdx.x < n;
-                if (alive) { xb[dest] = o.x; xb[WGT + dest] = o.y; xb[2 * WGT + dest] = o.z; xs[dest] = slot; }
-                __syncthreads();
-                if (has) { o = V3{xb[threadIdx.x], xb[WGT + threadIdx.x], xb[2 * WGT + threadIdx.x]}; slot = xs[threadIdx.x]; }
-                __syncthreads();
-                if (alive) { xb[dest] = d.x; xb[WGT + dest] = d.y; xb[2 * WGT + dest] = d.z; }
-                __syncthreads();
-                if (has) d = V3{xb[threadIdx.x], xb[WGT + threadIdx.x], xb[2 * WGT + threadIdx.x]};
-                __syncthreads();                                              // (trace_bounce parks directions in the same buffer)
-                alive = has;
-                holding = need;
-            }
-            const bool was = alive;
-            V3 rgb{0.0, 0.0, 0.0};
-            if (wave < holding)                                               // wave-uniform
-                trace_bounce<true, WGT, false, true>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
-            if (was) {                                                        // :120 / :131 (a bounce that missed adds pow * 0)
-                if (b == 0) { accp[slot] = rgb.x; accp[WGT + slot] = rgb.y; accp[2 * WGT + slot] = rgb.z; }
-                else {
-                    const double wgt = p.refl_pow[b - 1];
-                    accp[slot] = accp[slot] + wgt * rgb.x;
-                    accp[WGT + slot] = accp[WGT + slot] + wgt * rgb.y;
-                    accp[2 * WGT + slot] = accp[2 * WGT + slot] + wgt * rgb.z;
-                }
-            }
-        }
-        __syncthreads();                                                      // every path of the sample has ended: the colours are complete
-        if constexpr (AA) {
-            const V3 sC{accp[threadIdx.x], accp[WGT + threadIdx.x], accp[2 * WGT + threadIdx.x]};
-            if (tap == 0) taps.set(sC);
-            else if (stoch) { const V3 a = taps.get(); taps.set(V3{a.x + sC.x, a.y + sC.y, a.z + sC.z}); }
-            else if (interior) { const V3 a = taps.get(); taps.set(V3{a.x + sC.x, a.y + sC.z, a.z + sC.y}); }   // kernels.py:58-60 (G += B_s; B += G_s)
-            __syncthreads();                                                  // the next sample reuses the colour slots
-        }
-    }
-    double R, G, B;
-    if constexpr (AA) {
-        const V3 a = taps.get(); R = a.x; G = a.y; B = a.z;
-        if (stoch) { const double nn = (double)p.spp; R = R / nn; G = G / nn; B = B / nn; }
-        else if (interior) { R = R / 9; G = G / 9; B = B / 9; }               // kernels.py:63-65
-    } else { R = accp[threadIdx.x]; G = accp[WGT + threadIdx.x]; B = accp[2 * WGT + threadIdx.x]; }
-    if (inb) {
-        const long long off = (long long)(x - p.x0) * p.h + y;
-        if constexpr (LAT) {
-            double *q = p.out_f64 + off * 3;
-            q[0] = R; q[1] = G; q[2] = B;
-        } else {
-            const long long fo = opaque(p.nframes) > 1 ? (long long)((int)blockIdx.x / p.bpf) * p.frame_stride : 0ll;
-            store_pixel(p, off, fo, R, G, B);
-        }
-    }
+    const bool go = alive && p.depth >= p.wf_split;                           // the path goes on: queue it for bounce wf_split
+    wf_append(p, go, o, d, acc, pix, p.wf_split);
+    if (mine && !go) { double *q = p.wf_acc + (size_t)pix * 3; q[0] = acc.x; q[1] = acc.y; q[2] = acc.z; }
     if ((p.tile_cycles || p.cost) && lane == 0) {                             // timing only; never feeds a pixel
         const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
-        if (p.tile_cycles && tile < p.ntiles) p.tile_cycles[tile] = cyc;
+        if (p.tile_cycles) p.tile_cycles[tile] = cyc;
         if (p.cost) {
+            const int expected = (p.ntiles - block * WPW < WPW) ? p.ntiles - block * WPW : WPW;
             atomicAdd(&wgstat[0], cyc >> 2);
-            if ((int)atomicAdd(&wgstat[1], 1u) == WPW - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
+            if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
         }
     }
+}
+
+__global__ __launch_bounds__(WF_THREADS, RT_W_LANES) void wf_level_kernel(const KParams p)
+{
+    const Lds lds = wf_stage(p, WF_THREADS);
+    const int lane = threadIdx.x & 63;
+    const int level = p.wf_level;
+    const unsigned n_in = p.wf_cnt[level];
+    const double wgt = p.refl_pow[level - 1];
+    RayCount<false> cnt;
+    for (;;) {
+        unsigned c = 0;
+        if (lane == 0) c = atomicAdd(&p.wf_cnt[32 + level], 1u);
+        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+        if ((unsigned long long)c * 64ull >= n_in) break;                     // every wave ends here: the counter only grows
+        const long long i = (long long)c * 64 + lane;
+        bool alive = i < (long long)n_in;
+        const long long j = alive ? i : 0;
+        const double *q = p.wf_in + j;
+        V3 o{q[0], q[p.wf_cap], q[2 * p.wf_cap]}, d{q[3 * p.wf_cap], q[4 * p.wf_cap], q[5 * p.wf_cap]};
+        V3 acc{q[6 * p.wf_cap], q[7 * p.wf_cap], q[8 * p.wf_cap]};
+        const int pix = p.wf_pix_in[j];
+        const bool was = alive;
+        V3 rgb;
+        trace_bounce<false, WF_THREADS, false, true>(lds, p, alive, -1, o, d, rgb, cnt);
+        acc = V3{acc.x + wgt * rgb.x, acc.y + wgt * rgb.y, acc.z + wgt * rgb.z};   // trace.py:131 (a bounce that missed adds pow * 0)
+        const bool go = alive && level < p.depth;
+        wf_append(p, go, o, d, acc, pix, level + 1);
+        if (was && !go) { double *f = p.wf_acc + (size_t)pix * 3; f[0] = acc.x; f[1] = acc.y; f[2] = acc.z; }
+    }
+}
+
+// one thread per pixel of the launch's slab, y fastest: the finished colour of this pass's sample -> the pixel
+// (kernels.py:58-73; the tap order and the G/B swap of the 9-tap mode as in render_kernel)
+__global__ __launch_bounds__(256) void wf_resolve_kernel(const KParams p)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)(p.x1 - p.x0) * p.h) return;
+    const double *a = p.wf_acc + (size_t)idx * 3;
+    double R = a[0], G = a[1], B = a[2];
+    if (p.wf_ntaps > 1) {
+        const int xr = (int)(idx / p.h), y = (int)(idx - (long long)xr * p.h), x = p.x0 + xr;
+        const bool stoch = p.aa == 2;
+        const bool interior = x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
+        double *t = p.wf_taps + (size_t)idx * 3;
+        if (p.wf_tap == 0) { t[0] = R; t[1] = G; t[2] = B; }
+        else if (stoch) { R = t[0] + R; G = t[1] + G; B = t[2] + B; t[0] = R; t[1] = G; t[2] = B; }
+        else if (interior) { const double r2 = t[0] + R, g2 = t[1] + B, b2 = t[2] + G; R = r2; G = g2; B = b2; t[0] = R; t[1] = G; t[2] = B; }   // G += B_s; B += G_s
+        else { R = t[0]; G = t[1]; B = t[2]; }
+        if (p.wf_tap != p.wf_ntaps - 1) return;
+        if (stoch) { const double n = (double)p.wf_ntaps; R = R / n; G = G / n; B = B / n; }
+        else if (interior) { R = R / 9; G = G / 9; B = B / 9; }               // kernels.py:63-65
+    }
+    store_pixel(p, idx, 0ll, R, G, B);
 }
 
 // RT_AA_REFERENCE, second half (kernels.py:29-65): pixel (x,y) sums the lattice samples around its centre (2x, 2y) in the
