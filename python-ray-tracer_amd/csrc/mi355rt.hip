@@ -73,7 +73,7 @@ struct rt_ctx {
     double cam_o[3] = {0, 0, 0}, cam_R[9] = {0};
     int w = 0, h = 0;
     double px = 0, y0 = 0, dy = 0, z0 = 0, dz = 0;
-    size_t lds_limit_set = 0, lds_limit_wf = 0;
+    size_t lds_limit_set = 0;
     unsigned plane_codes = 0;         // axis codes of planes 0..3 (rt_device.h: KParams::plane_codes)
     unsigned *tile_stats = nullptr;   // caller-owned device buffer or NULL
     // Scheduler feedback: a MEASURING launch stores its tile blocks' costs; a small kernel behind it (same stream) turns
@@ -112,12 +112,6 @@ struct rt_ctx {
     rt_stats stats = {};              // host-side launch counters (the ray counters live in `counts`)
     Buf counts;                       // 4 x uint64 on the device: ray counters of RT_FLAG_COUNT_RAYS launches
     std::vector<std::pair<hipStream_t, Buf>> lattice;   // per launching stream: float64 lattice samples (RT_AA_REFERENCE)
-    // Wavefront path of the large clustered scenes (rt_device.h: wf_*_kernel): per launching stream two ray queues, the
-    // finished colours, the anti-aliasing sums and the queue counters, sized for the largest launch seen on that stream
-    struct WfBuf { hipStream_t stream = nullptr; Buf q[2], pix[2], acc, taps, cnt; };
-    std::vector<WfBuf> wf;
-    int wavefront = 1;                // MI355RT_WAVEFRONT=0: round 2's one-wave-per-tile-for-the-whole-path kernels (A/B)
-    int wf_split = 2;                 // MI355RT_WF_SPLIT: bounces the primary kernel traces before paths are queued
     int cu_count = 256;
     unsigned long long epoch = 1;     // bumped by every rt_set_*: scene, camera or ray grid changed
     unsigned long long scene_epoch = 1;   // bumped by rt_set_scene only
@@ -354,62 +348,6 @@ int launch(rt_ctx *ctx, const rt_params *p, int x0, int x1, void *d_u8, void *d_
     return dispatch(ctx, p, k, false, stream, nframes, frame_stride);
 }
 
-// The wavefront path of one frame (rt_device.h: wf_primary_kernel, wf_level_kernel, wf_resolve_kernel) on `stream`:
-// per sample of a pixel, the primary kernel (grid = tile blocks, in the dispatch order k carries), one persistent launch
-// per later bounce, and the resolve.  k.out_f64 != nullptr: a lattice launch — the finished colours ARE the lattice samples.
-int launch_wavefront(rt_ctx *ctx, rt::KParams &k, bool lattice, unsigned grid, size_t lds, hipStream_t stream)
-{
-    rt_ctx::WfBuf *wb = nullptr;
-    for (auto &c : ctx->wf) if (c.stream == stream) { wb = &c; break; }
-    if (!wb) {
-        try { ctx->wf.emplace_back(); } catch (const std::bad_alloc &) { return fail(ctx, RT_ERR_ALLOC, "out of host memory"); }
-        wb = &ctx->wf.back();
-        wb->stream = stream;
-    }
-    const size_t cap = (size_t)(k.x1 - k.x0) * (size_t)k.h;
-    const int ntaps = lattice ? 1 : (k.aa == RT_AA_REFERENCE ? 9 : (k.aa == RT_AA_STOCHASTIC ? k.spp : 1));
-    const bool levels = k.depth >= ctx->wf_split;
-    const size_t need_q = levels ? cap * rt::WF_COMP * sizeof(double) : 16, need_pix = levels ? cap * sizeof(int) : 16;
-    const size_t need_acc = lattice ? 0 : cap * 3 * sizeof(double), need_taps = ntaps > 1 ? cap * 3 * sizeof(double) : 0;
-    if (wb->q[0].cap < need_q || wb->pix[0].cap < need_pix || wb->acc.cap < need_acc || wb->taps.cap < need_taps)
-        RT_HIP(ctx, hipStreamSynchronize(stream));             // growing frees the old buffers
-    int rc = RT_OK;
-    for (int i = 0; i < 2 && rc == RT_OK; ++i) { rc = ensure(ctx, wb->q[i], need_q); if (rc == RT_OK) rc = ensure(ctx, wb->pix[i], need_pix); }
-    if (rc == RT_OK && need_acc) rc = ensure(ctx, wb->acc, need_acc);
-    if (rc == RT_OK && need_taps) rc = ensure(ctx, wb->taps, need_taps);
-    if (rc == RT_OK) rc = ensure(ctx, wb->cnt, 64 * sizeof(unsigned));
-    if (rc != RT_OK) return rc;
-    k.wf_cap = (long long)cap; k.wf_split = ctx->wf_split; k.wf_ntaps = ntaps;
-    k.wf_cnt = (unsigned *)wb->cnt.p;
-    k.wf_acc = lattice ? k.out_f64 : (double *)wb->acc.p;
-    k.wf_taps = (double *)wb->taps.p;
-    k.nframes = 1;
-    const void *prim = lattice ? (const void *)rt::wf_primary_kernel<true> : (const void *)rt::wf_primary_kernel<false>;
-    const unsigned persistent = (unsigned)(ctx->cu_count * RT_W_LANES);      // workgroups that are resident together
-    for (int t = 0; t < ntaps; ++t) {
-        RT_HIP(ctx, hipMemsetAsync(wb->cnt.p, 0, 64 * sizeof(unsigned), stream));
-        k.wf_tap = t;
-        k.wf_out = (double *)wb->q[0].p; k.wf_pix_out = (int *)wb->pix[0].p;
-        void *args[] = {(void *)&k};
-        RT_HIP(ctx, hipLaunchKernel(prim, dim3(grid), dim3(rt::WF_THREADS), args, lds, stream));
-        rt::KParams kl = k;
-        kl.cost = nullptr; kl.tile_cycles = nullptr;
-        for (int l = ctx->wf_split, i = 0; l <= k.depth; ++l, i ^= 1) {
-            kl.wf_level = l;
-            kl.wf_in = (double *)wb->q[i].p; kl.wf_pix_in = (int *)wb->pix[i].p;
-            kl.wf_out = (double *)wb->q[i ^ 1].p; kl.wf_pix_out = (int *)wb->pix[i ^ 1].p;
-            void *largs[] = {(void *)&kl};
-            RT_HIP(ctx, hipLaunchKernel((const void *)rt::wf_level_kernel, dim3(persistent), dim3(rt::WF_THREADS), largs, lds, stream));
-        }
-        if (!lattice) {
-            const long long npx = (long long)cap;
-            hipLaunchKernelGGL(rt::wf_resolve_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, k);
-            RT_HIP(ctx, hipGetLastError());
-        }
-    }
-    return RT_OK;
-}
-
 // Chooses the kernel instantiation and the dispatch order for one launch of the render kernel over the tiles k
 // describes, and launches it.
 int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipStream_t stream, int nframes, int64_t frame_stride)
@@ -438,13 +376,6 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool park = !count && (lanes ? (lds_park * RT_W_LANES <= 160 * 1024 && ctx->lanes_park) : lds_park * (24 / wpw) <= 160 * 1024);
     const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, ltab, lanes);
     const void *fn = lanes ? lanes_variant(aa, lattice, park) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
-    const bool wavefront = lanes && ctx->wavefront;            // bounce by bounce over ray queues (rt_device.h: wf_*_kernel)
-    const size_t lds_wf = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, false, false, rt::WF_THREADS, ltab, true);
-    if (wavefront && lds_wf > 48 * 1024 && lds_wf > ctx->lds_limit_wf) {
-        for (const void *f_ : {(const void *)rt::wf_primary_kernel<true>, (const void *)rt::wf_primary_kernel<false>, (const void *)rt::wf_level_kernel})
-            RT_HIP(ctx, hipFuncSetAttribute(f_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wf));
-        ctx->lds_limit_wf = lds_wf;
-    }
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -527,7 +458,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool settled = feedback && f.have && (same_epoch ? f.builds >= 2 : f.since < ctx->remeasure);
     // A launch of several frames (rt_render_sequence) is ONE launch only in a settled order; until then its frames go
     // through this function one by one (a measuring launch stores the costs of one frame).
-    if (nframes > 1 && (!settled || wavefront || (long long)grid * nframes >= (1ll << 31))) {
+    if (nframes > 1 && (!settled || (long long)grid * nframes >= (1ll << 31))) {
         for (int fr = 0; fr < nframes; ++fr) {
             rt::KParams kf = k;
             if (kf.out_u8) kf.out_u8 += (size_t)fr * frame_stride;
@@ -559,13 +490,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         k.cost = (unsigned *)f.cost.p;
     }
     k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride; k.seq_offset = (ctx->seq_order < 0 ? wpw == 2 : ctx->seq_order != 0) ? (int)grid : 0;
-    if (wavefront) {
-        int rcw = launch_wavefront(ctx, k, lattice, grid, lds_wf, stream);
-        if (rcw != RT_OK) return rcw;
-    } else {
-        void *args[] = {(void *)&k};
-        RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid * (unsigned)nframes), dim3(wgt), args, lds, stream));
-    }
+    void *args[] = {(void *)&k};
+    RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid * (unsigned)nframes), dim3(wgt), args, lds, stream));
     ctx->stats.launches++;
     ctx->stats.frames += (uint64_t)nframes;
     if (settled) ctx->stats.launches_settled++;
@@ -616,8 +542,6 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_REMEASURE")) ctx->remeasure = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("MI355RT_WAVEFRONT")) ctx->wavefront = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MI355RT_WF_SPLIT")) ctx->wf_split = std::min(std::max(1, std::atoi(e)), RT_MAX_DEPTH + 1);
     if (const char *e = std::getenv("MI355RT_LANES_PARK")) ctx->lanes_park = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI355RT_SEQ_ORDER")) ctx->seq_order = std::atoi(e) != 0 ? 1 : 0;
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }
@@ -646,7 +570,6 @@ int rt_destroy(rt_ctx *ctx)
         if (b->p) (void)hipFree(b->p);
     for (Buf &b : ctx->scene) if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->lattice) if (e.second.p) (void)hipFree(e.second.p);
-    for (auto &wb : ctx->wf) for (Buf *b : {&wb.q[0], &wb.q[1], &wb.pix[0], &wb.pix[1], &wb.acc, &wb.taps, &wb.cnt}) if (b->p) (void)hipFree(b->p);
     for (auto &f : ctx->fbs) {
         for (Buf *b : {&f.cost, &f.gtmp, &f.btmp, &f.order[0], &f.order[1]}) if (b->p) (void)hipFree(b->p);
         for (auto &r : f.fence) (void)hipEventDestroy(r.second);
@@ -1146,13 +1069,6 @@ static int forget_stream(rt_ctx *ctx, hipStream_t stream)
         f.users.erase(std::remove(f.users.begin(), f.users.end(), stream), f.users.end());
     }
     for (auto &rd : ctx->scene_readers) rd.erase(std::remove(rd.begin(), rd.end(), stream), rd.end());
-    for (size_t i = 0; i < ctx->wf.size();) {
-        if (ctx->wf[i].stream == stream) {
-            for (Buf *b : {&ctx->wf[i].q[0], &ctx->wf[i].q[1], &ctx->wf[i].pix[0], &ctx->wf[i].pix[1], &ctx->wf[i].acc, &ctx->wf[i].taps, &ctx->wf[i].cnt})
-                if (b->p) (void)hipFree(b->p);
-            ctx->wf.erase(ctx->wf.begin() + (long)i);
-        } else ++i;
-    }
     for (size_t i = 0; i < ctx->tables.size();) {               // the stream's own cull-table sets go with it
         if (ctx->tables[i].stream == stream) {
             for (auto &t : ctx->tables[i].sets) if (t.buf.p) (void)hipFree(t.buf.p);

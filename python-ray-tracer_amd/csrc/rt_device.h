@@ -87,14 +87,6 @@ struct KParams {
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs (XCD-affine, longest
                                // first inside every XCD); order + bpf: the same XCD assignment in plain tile order, which all but the
                                // last frame of a multi-frame launch use (order_kernel)
-    // Wavefront path of the large clustered scenes (wf_primary_kernel / wf_level_kernel / wf_resolve_kernel):
-    double *wf_in, *wf_out;    // ray queues, structure of arrays: component c (o.xyz, d.xyz, colour.xyz) of ray i at q[c * wf_cap + i]
-    int *wf_pix_in, *wf_pix_out;   // the pixel (offset within the launch's slab) each queued ray belongs to
-    unsigned *wf_cnt;          // [l] rays queued for bounce l; [32 + l] chunks of bounce l handed out so far (zeroed per sample pass)
-    double *wf_acc;            // finished paths: float64 (R,G,B) per pixel, [pixel][3]
-    double *wf_taps;           // AA modes: the running sum over the samples of a pixel
-    long long wf_cap;
-    int wf_level, wf_split, wf_tap, wf_ntaps;
     int seq_offset;            // bpf, or 0 to dispatch every frame of a multi-frame launch longest-first (MI355RT_SEQ_ORDER=0)
     int nframes, bpf;          // frames rendered by this launch (rt_render_sequence) and workgroups per frame: workgroup b renders
                                // block order[b % bpf] of frame b / bpf into the outputs + (b / bpf) * frame_stride elements
@@ -1489,189 +1481,6 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
             if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Wavefront path of the large clustered scenes (lane-owned traversal, MODE 2; from 161 spheres on).
-//
-// A path ends when a bounce misses (trace.py:124-126).  With one wave per 8x8 tile for the whole path (round 2), config 5's
-// waves ran bounces 2..8 with 0.95, 0.85, 0.72, 0.57, 0.44, 0.34, 0.26 of their lanes, and — worse — the few waves that
-// still had a live path kept their workgroup's slot while its other waves had finished: bounce 8 cost 0.6 ms for 1.5 million
-// rays where bounce 0 cost 2.4 ms for 33 million primary and 80 million shadow rays (profiles/r02_c5/depth_sweep.txt).
-// Here the frame is rendered bounce by bounce over QUEUES of live rays in HBM (sized for the whole frame: 288 GB are there
-// to be used):
-//   wf_primary_kernel   one wave per tile as before: ray generation and the first wf_split bounces (0 and 1, where every
-//                       lane has a path); a path that is still alive is appended to the queue of bounce wf_split —
-//                       origin, direction, colour so far, pixel — and a path that has ended leaves its colour in wf_acc;
-//   wf_level_kernel     one launch per later bounce, persistent workgroups (the scene image is staged ONCE per workgroup):
-//                       every wave takes chunks of 64 consecutive queued rays — all lanes live — traces the bounce, adds
-//                       refl**l times its colour (trace.py:131: the sum is sequential per path, and a path's bounces run in
-//                       consecutive launches), and appends the survivors, compacted by a ballot and ONE atomic per wave, to
-//                       the next bounce's queue;
-//   wf_resolve_kernel   clips and stores the pixels (kernels.py:69-73), or — anti-aliasing modes — folds the sample into the
-//                       pixel's running sum in the reference's order (one pass of the three kernels per sample).
-// The same float64 operations on the same values in the same order per path: frames are bit-identical.  Queue traffic:
-// 76 bytes per live ray and bounce, written once and read once, coalesced (structure of arrays).
-// ---------------------------------------------------------------------------------------------
-constexpr int WF_COMP = 9;                   // doubles per queued ray
-constexpr int WF_THREADS = 256;
-
-// the survivors of a wave -> consecutive entries of the next queue (one atomic per wave)
-__device__ __forceinline__ void wf_append(const KParams &p, bool go, const V3 &o, const V3 &d, const V3 &c, int pix, int level)
-{
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(go);
-    if (m == 0ull) return;                                                    // wave-uniform
-    unsigned base = 0;
-    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&p.wf_cnt[level], (unsigned)__builtin_popcountll(m));
-    base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
-    if (go) {
-        const long long i = (long long)base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        double *q = p.wf_out + i;
-        q[0] = o.x; q[p.wf_cap] = o.y; q[2 * p.wf_cap] = o.z;
-        q[3 * p.wf_cap] = d.x; q[4 * p.wf_cap] = d.y; q[5 * p.wf_cap] = d.z;
-        q[6 * p.wf_cap] = c.x; q[7 * p.wf_cap] = c.y; q[8 * p.wf_cap] = c.z;
-        p.wf_pix_out[i] = pix;
-    }
-}
-
-// stages the MODE 2 LDS image (planes' and lights' records + the float32 tables) and returns the table pointers
-__device__ __forceinline__ Lds wf_stage(const KParams &p, int wg_threads)
-{
-    const int nrec = (int)lds_doubles(0, p.P, p.L);
-    const double *rec_src = p.scene + (size_t)p.S * SPH_STRIDE;
-    float *sph32 = reinterpret_cast<float *>(lds_raw + nrec);
-    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
-    const bool ltab = p.anchors > 0;
-    for (int i = threadIdx.x; i < nrec; i += wg_threads) lds_raw[i] = rec_src[i];
-    const int nf4 = (int)((ltab ? tl.total_lanes : tl.total) / 4);
-    const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
-    f4 *dst = reinterpret_cast<f4 *>(sph32);
-    for (int i = threadIdx.x; i < nf4; i += wg_threads) dst[i] = src[i];
-    __syncthreads();
-    return Lds{sph32, sph32 + tl.tab, ltab ? nullptr : sph32 + tl.csph32, sph32 + tl.ctab, sph32 + tl.cbox, sph32 + tl.gbox, sph32 + tl.gtab,
-               p.NC, true, nullptr};
-}
-
-template <bool LAT>
-__global__ __launch_bounds__(WF_THREADS, RT_W_LANES) void wf_primary_kernel(const KParams p)
-{
-    constexpr int WPW = WF_THREADS / 64;
-    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
-    unsigned *wgstat = reinterpret_cast<unsigned *>(reinterpret_cast<float *>(lds_raw + lds_doubles(0, p.P, p.L)) + (p.anchors > 0 ? tl.total_lanes : tl.total));
-    if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
-    const Lds lds = wf_stage(p, WF_THREADS);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int block = p.order ? (int)p.order[blockIdx.x] : (int)blockIdx.x;
-    const int tile = block * WPW + wave;
-    if (tile >= p.ntiles) return;                                             // whole wave, after the barrier
-    const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
-    const int x = p.x0 + tx * TILE + (lane >> 3);
-    const int y = ty * TILE + (lane & 7);
-    bool inb = (x < p.x1) && (y < p.h);
-    if constexpr (LAT) inb = inb && ((((x | y) & 1) == 0) || (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2));
-    const int xc = inb ? x : p.x0, yc = inb ? y : 0;
-    const int pix = (x - p.x0) * p.h + y;
-    // the sample of this pass (wf_tap): as render_kernel generates it
-    V3 Pt;
-    bool mine = inb;
-    if constexpr (LAT) Pt = lattice_P(p, xc, yc);
-    else {
-        const V3 Pp = pixel_P(p, xc, yc);                                     // kernels.py:19
-        Pt = Pp;
-        if (p.aa == 2) {
-            const unsigned hh = jitter_hash((unsigned)xc, (unsigned)yc, (unsigned)p.wf_tap, p.seed);
-            const double u = (double)(hh & 0xFFFFu) * 0x1p-16 + (0x1p-17 - 0.5);
-            const double v = (double)(hh >> 16) * 0x1p-16 + (0x1p-17 - 0.5);
-            Pt = V3{Pp.x, Pp.y + u * p.dy, Pp.z + v * p.dz};
-        } else if (p.aa == 1 && p.wf_tap) {
-            constexpr unsigned NBX = 0x8858u, NBY = 0x0A25u;                  // kernels.py:53 (see render_kernel)
-            const bool interior = inb && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
-            const int k = p.wf_tap - 1;
-            const int ddx = (int)((NBX >> (2 * k)) & 3u) - 1, ddy = (int)((NBY >> (2 * k)) & 3u) - 1;
-            const V3 Pn = pixel_P(p, interior ? x + ddx : xc, interior ? y + ddy : yc);
-            Pt = V3{0.5 * Pp.x + 0.5 * Pn.x, 0.5 * Pp.y + 0.5 * Pn.y, 0.5 * Pp.z + 0.5 * Pn.z};   // kernels.py:43-50
-            mine = interior;
-        }
-    }
-    V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]}, d = primary_dir(p, Pt);         // kernels.py:16, :22-23
-    bool alive = mine;
-    V3 acc{0.0, 0.0, 0.0};
-    RayCount<false> cnt;
-    const int last = p.depth < p.wf_split - 1 ? p.depth : p.wf_split - 1;
-    for (int b = 0; b <= last; ++b) {                                         // trace.py:120-131, the first bounces
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-        V3 rgb;
-        trace_bounce<false, WF_THREADS, false, true>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
-        if (b == 0) acc = rgb;
-        else { const double wgt = p.refl_pow[b - 1]; acc = V3{acc.x + wgt * rgb.x, acc.y + wgt * rgb.y, acc.z + wgt * rgb.z}; }
-    }
-    const bool go = alive && p.depth >= p.wf_split;                           // the path goes on: queue it for bounce wf_split
-    wf_append(p, go, o, d, acc, pix, p.wf_split);
-    if (mine && !go) { double *q = p.wf_acc + (size_t)pix * 3; q[0] = acc.x; q[1] = acc.y; q[2] = acc.z; }
-    if ((p.tile_cycles || p.cost) && lane == 0) {                             // timing only; never feeds a pixel
-        const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
-        if (p.tile_cycles) p.tile_cycles[tile] = cyc;
-        if (p.cost) {
-            const int expected = (p.ntiles - block * WPW < WPW) ? p.ntiles - block * WPW : WPW;
-            atomicAdd(&wgstat[0], cyc >> 2);
-            if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
-        }
-    }
-}
-
-__global__ __launch_bounds__(WF_THREADS, RT_W_LANES) void wf_level_kernel(const KParams p)
-{
-    const Lds lds = wf_stage(p, WF_THREADS);
-    const int lane = threadIdx.x & 63;
-    const int level = p.wf_level;
-    const unsigned n_in = p.wf_cnt[level];
-    const double wgt = p.refl_pow[level - 1];
-    RayCount<false> cnt;
-    for (;;) {
-        unsigned c = 0;
-        if (lane == 0) c = atomicAdd(&p.wf_cnt[32 + level], 1u);
-        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-        if ((unsigned long long)c * 64ull >= n_in) break;                     // every wave ends here: the counter only grows
-        const long long i = (long long)c * 64 + lane;
-        bool alive = i < (long long)n_in;
-        const long long j = alive ? i : 0;
-        const double *q = p.wf_in + j;
-        V3 o{q[0], q[p.wf_cap], q[2 * p.wf_cap]}, d{q[3 * p.wf_cap], q[4 * p.wf_cap], q[5 * p.wf_cap]};
-        V3 acc{q[6 * p.wf_cap], q[7 * p.wf_cap], q[8 * p.wf_cap]};
-        const int pix = p.wf_pix_in[j];
-        const bool was = alive;
-        V3 rgb;
-        trace_bounce<false, WF_THREADS, false, true>(lds, p, alive, -1, o, d, rgb, cnt);
-        acc = V3{acc.x + wgt * rgb.x, acc.y + wgt * rgb.y, acc.z + wgt * rgb.z};   // trace.py:131 (a bounce that missed adds pow * 0)
-        const bool go = alive && level < p.depth;
-        wf_append(p, go, o, d, acc, pix, level + 1);
-        if (was && !go) { double *f = p.wf_acc + (size_t)pix * 3; f[0] = acc.x; f[1] = acc.y; f[2] = acc.z; }
-    }
-}
-
-// one thread per pixel of the launch's slab, y fastest: the finished colour of this pass's sample -> the pixel
-// (kernels.py:58-73; the tap order and the G/B swap of the 9-tap mode as in render_kernel)
-__global__ __launch_bounds__(256) void wf_resolve_kernel(const KParams p)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)(p.x1 - p.x0) * p.h) return;
-    const double *a = p.wf_acc + (size_t)idx * 3;
-    double R = a[0], G = a[1], B = a[2];
-    if (p.wf_ntaps > 1) {
-        const int xr = (int)(idx / p.h), y = (int)(idx - (long long)xr * p.h), x = p.x0 + xr;
-        const bool stoch = p.aa == 2;
-        const bool interior = x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
-        double *t = p.wf_taps + (size_t)idx * 3;
-        if (p.wf_tap == 0) { t[0] = R; t[1] = G; t[2] = B; }
-        else if (stoch) { R = t[0] + R; G = t[1] + G; B = t[2] + B; t[0] = R; t[1] = G; t[2] = B; }
-        else if (interior) { const double r2 = t[0] + R, g2 = t[1] + B, b2 = t[2] + G; R = r2; G = g2; B = b2; t[0] = R; t[1] = G; t[2] = B; }   // G += B_s; B += G_s
-        else { R = t[0]; G = t[1]; B = t[2]; }
-        if (p.wf_tap != p.wf_ntaps - 1) return;
-        if (stoch) { const double n = (double)p.wf_ntaps; R = R / n; G = G / n; B = B / n; }
-        else if (interior) { R = R / 9; G = G / 9; B = B / 9; }               // kernels.py:63-65
-    }
-    store_pixel(p, idx, 0ll, R, G, B);
 }
 
 // RT_AA_REFERENCE, second half (kernels.py:29-65): pixel (x,y) sums the lattice samples around its centre (2x, 2y) in the
