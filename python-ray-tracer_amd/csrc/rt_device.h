@@ -278,11 +278,33 @@ struct Lds {
     const float *gtab;     // anchors x pad4(supers(NC)) x CULL_STRIDE: the groups' bounding spheres, anchored form
     int NC;
     bool groups;           // a compile-time constant per kernel: test a chunk's group of clusters before its clusters (MODE 2 kernels)
+#ifdef RT_REGION_STATS
+    unsigned *reg;         // measurement build: 32 words per wave — cycles per code region [0, 24), bounce class [30], last stamp [31]
+#endif
     double *acc;           // 6 (9 with AA) x workgroup-size doubles, [slot][thread] (consecutive lanes -> consecutive banks):
                            // slots 0-2 the running colour of the current sample, 3-5 the incoming direction
                            // during the light loop, 6-8 (AA kernel only) the tap sums — kept out of VGPRs that would stay
                            // live across every query of every bounce (registers decide occupancy here)
 };
+
+#ifdef RT_REGION_STATS
+// Measurement build only (hipcc -DRT_REGION_STATS, tools/region_stats.py): where a wave's cycles go.  RT_MARK(id) adds the
+// shader-clock cycles since the wave's previous mark to region `id` (+ 12 for bounces 2 and later); all active lanes write
+// the same values to the wave's words.  Regions: 0 re-normalise (closest), 1 closest: cluster bounds, 2 closest: cluster
+// loop (float32 sphere tests + float64 tests), 3 closest: planes + select, 4 hit point / normal, 5 light direction + Lambert,
+// 6 re-normalise (shadow), 7 shadow: cluster bounds, 8 shadow: cluster loop, 9 shadow: planes, 10 reflection, 11 the rest.
+__device__ __forceinline__ void region_mark(unsigned *reg, int id)
+{
+    volatile unsigned *r = reg + (threadIdx.x >> 6) * 32;
+    const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned last = r[31], c = r[30];
+    r[id + c] = r[id + c] + (now - last);
+    r[31] = now;
+}
+#define RT_MARK(id) region_mark(lds.reg, id)
+#else
+#define RT_MARK(id)
+#endif
 
 struct RayF {              // float32 shadow of a query, for the cull only
     F3 o, R;
@@ -798,6 +820,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
     for (int cb = 0; cb < lds.NC; cb += 32) {
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
         unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, p.extent2);
+        RT_MARK(1);
 #ifdef RT_LANE_STATS
         lane_stats(p, 0, __builtin_popcount(cm));
 #endif
@@ -824,6 +847,7 @@ __device__ __forceinline__ void lanes_closest(const Lds &lds, const KParams &p, 
             lane_stats(p, 4, smc);
 #endif
         }
+        RT_MARK(2);
     }
 }
 
@@ -846,6 +870,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
         unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, p.extent2);
+        RT_MARK(7);
         if (occ) cm = 0u;
 #ifdef RT_LANE_STATS
         lane_stats(p, 8, __builtin_popcount(cm));
@@ -874,6 +899,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
             lane_stats(p, 12, smc);
 #endif
         }
+        RT_MARK(8);
     }
     return occ;
 }
@@ -889,6 +915,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     const int S = p.S;
     const V3 R = renormalize_unit(d);                         // R == normalize(d), intersections.py:13
     const double a = dot3(R, R);
+    RT_MARK(0);
 #if RT_PREFILTER
     const int canchor = (opaque(p.anchors) > 0) ? anchor : -1;
 #endif
@@ -934,6 +961,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
         }
     }
     t_out = best; idx_out = idx; type_out = type;
+    RT_MARK(3);
 }
 
 // trace.py:92-96: the shadow query only asks "does anything report 0 < t < 999" (any hit).
@@ -951,6 +979,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
     // rounding the margins already budget for) and R, a are formed only if some lane's mask is not empty
     constexpr bool LAZY = RT_LAZY_RENORM && MODE == 0;
     if (!LAZY) { R = renormalize_unit(d); a = dot3(R, R); }  // R == normalize(d), intersections.py:13
+    RT_MARK(6);
     bool a_sane = (a > 0.999999 && a < 1.000001);
     bool haveR = !LAZY;
     bool occ = false;
@@ -997,6 +1026,7 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
             }
         }
     }
+    RT_MARK(9);
     return occ;
 }
 
@@ -1024,6 +1054,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
+    RT_MARK(11);
     if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type);   // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
@@ -1059,6 +1090,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         const int self = (type == HIT_SPHERE) ? idx : -1;
         Park3<PARK, WGT> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
         dpark.set(d);
+        RT_MARK(4);
 
         const double *lt = lds.recs() + plb + opaque(P) * PL_STRIDE;
         for (int m = 0; m < L; ++m) {                                         // :86-102
@@ -1068,6 +1100,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             // :92-102 — the shadow query's answer is only used when k > 0; it has no other effect,
             // so lanes with k <= 0 (light behind the surface) do not ask.
             cnt.shadow(true, k > 0.0);
+            RT_MARK(5);
             if (k > 0.0) {
                 // (the shadow rays of the primary hits still travel together: wave-uniform cull unless p.lanes_primary)
                 const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, anchor != 0 || p.lanes_primary);
@@ -1081,6 +1114,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         const V3 Rd = renormalize_unit(V3{d.x + c2 * N.x, d.y + c2 * N.y, d.z + c2 * N.z});
         o = V3{Pt.x + 0.0002 * Rd.x, Pt.y + 0.0002 * Rd.y, Pt.z + 0.0002 * Rd.z};   // :110
         d = Rd;
+        RT_MARK(10);
     }
 }
 
@@ -1101,6 +1135,9 @@ __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool aliv
             }
         }
         V3 rgb;
+#ifdef RT_REGION_STATS
+        ((volatile unsigned *)lds.reg)[(threadIdx.x >> 6) * 32 + 30] = b >= 2 ? 12u : 0u;
+#endif
         trace_bounce<PARK, WGT, COUNT, MODE == 2>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
@@ -1221,7 +1258,11 @@ __host__ __device__ inline size_t table_floats(int S, int NC, int anchors, bool 
 __host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool lanes = false, bool mode2 = false)
 {
     return (lds_doubles(mode2 ? 0 : S, P, L) + (size_t)lds_slots(aa, park, mode2) * wgt) * sizeof(double) +
-           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16;   // + workgroup cost/arrival words
+           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16   // + workgroup cost/arrival words
+#ifdef RT_REGION_STATS
+           + (size_t)(wgt / 64) * 32 * sizeof(unsigned)
+#endif
+           ;
 }
 
 // The float32 cull tables (exact sphere table for the origin form; {A-c, tau} per anchor and sphere; the same two
@@ -1373,7 +1414,13 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // two-wave workgroups serve the small flat scenes only (the host sends every clustered scene to workgroups of 4): with
     // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
     // register optimum)
+#ifdef RT_REGION_STATS
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, MODE >= 2, wgstat + 4, accum};
+    for (int i = threadIdx.x & 63; i < 32; i += 64) lds.reg[(threadIdx.x >> 6) * 32 + i] = 0u;
+    if ((threadIdx.x & 63) == 0) lds.reg[(threadIdx.x >> 6) * 32 + 31] = (unsigned)__builtin_amdgcn_s_memtime();
+#else
     const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, MODE >= 2, accum};
+#endif
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Longest-first dispatch: the hardware hands out workgroups in blockIdx order, so blockIdx indexes a
@@ -1462,6 +1509,11 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
             store_pixel(p, off, fo, R, G, B);
         }
     }
+#ifdef RT_REGION_STATS
+    RT_MARK(11);
+    if (p.tile_cycles && (threadIdx.x & 63) < 24)                            // behind the per-tile cycles: 24 region counters (cycles / 64)
+        atomicAdd(p.tile_cycles + p.ntiles + 16 + (threadIdx.x & 63), lds.reg[(threadIdx.x >> 6) * 32 + (threadIdx.x & 63)] >> 6);
+#endif
     if constexpr (COUNT) {                                                    // rt_get_stats: one atomic per wave and counter
         unsigned v[4] = {cnt.n_closest, cnt.n_issued, cnt.n_skipped, cnt.n_hit};
 #pragma unroll
