@@ -333,11 +333,16 @@ def main():
         kernel_ms = sum(spans) / max(len(spans), 1) / max(1.0, nl / NS)
     if not use_gather:
         frame = pipe.last_slab()[:, :ws]
+        frame32 = pipe.last_slab_f32()[:, :ws]
     elif pipe.rotate_root:                              # the last batch was assembled on its own root: rank 0 checks it
         last_root = (pipe.batches - 1) % world
         buf = frame.clone() if rank == last_root else torch.empty((3, w, h), dtype=torch.uint8, device=dev)
         dist.broadcast(buf, src=last_root)
         frame = buf
+        if a.gather == "f32":
+            buf32 = frame32.clone() if rank == last_root else torch.empty((3, w, h), dtype=torch.float32, device=dev)
+            dist.broadcast(buf32, src=last_root)
+            frame32 = buf32
 
     mine = torch.tensor([dt, kernel_ms, (t_submitted - t0) / a.steps * 1e3, float(x0), float(x1)], dtype=torch.float64, device=dev)
     per_rank = None
@@ -373,10 +378,15 @@ def main():
         tr = stamped(os.path.join(REPO, "profiles", f"traffic_{ROUND}{suffix}.json"), so_sha) if world == 1 else None
         traffic = tr.get("hbm_bytes_per_launch") if tr else None
         frame_host = frame.cpu().numpy()
-        check = None
+        check = check32 = None
         gpath = os.path.join(REPO, "tests", "golden", "frame_c2_1080p.npz")
         if name == workloads.HEADLINE and os.path.exists(gpath):
-            check = hashlib.sha256(frame_host.tobytes()).hexdigest() == str(np.load(gpath)["sha256_u8"])
+            gold = np.load(gpath)
+            check = hashlib.sha256(frame_host.tobytes()).hexdigest() == str(gold["sha256_u8"])
+            # the float32 pre-clip planes (north_star's tolerance is stated on them): this rank's own at N = 1, the ASSEMBLED
+            # frame with --gather f32
+            if frame32 is not None and tuple(frame32.shape) == (3, w, h):
+                check32 = hashlib.sha256(np.ascontiguousarray(frame32.cpu().numpy()).tobytes()).hexdigest() == str(gold["sha256_rgb32"])
 
         # -- what the kernel really traced (counting instantiation, one frame, outside the timed region)
         traced = None
@@ -488,6 +498,7 @@ def main():
             "frames_per_launch": round(fpl, 3), "launches": len(per_launch) if per_launch else None,
             "per_rank": per_rank,
             "frame_matches_reference_sha256": check,
+            "float32_frame_matches_reference_sha256": check32,
             "slab_balance": balance,
             "dynamic": dynamic,
             "host_path_ms": host_path,

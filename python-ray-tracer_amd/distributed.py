@@ -213,7 +213,7 @@ class SequencePipeline:
         self.count = [0] * self.SLOTS
         self.n = 0                              # position in the slot/batch cycle (padded to a batch boundary by drain())
         self.index = 0                          # frames submitted so far
-        self._last = None
+        self._last = self._last32 = None
 
     def stream_handle(self, i):
         return self.handles[i % self.NS]
@@ -261,12 +261,14 @@ class SequencePipeline:
         slot, j = (i // self.F) % self.SLOTS, i % self.F
         if self.gatherer is None:
             self._last = self.u8v[slot][j]
-            launch(self._last, self.f32v[slot][j] if self.f32v is not None else None, handle)
+            self._last32 = self.f32v[slot][j] if self.f32v is not None else None
+            launch(self._last, self._last32, handle)
             return
         if j == 0:
             self._open_batch(slot, idx)
         self._last = self.u8v[slot][j]
-        launch(self._last, self.f32v[slot][j] if self.f32v is not None else None, handle)
+        self._last32 = self.f32v[slot][j] if self.f32v is not None else None
+        launch(self._last, self._last32, handle)
         self.count[slot] += 1
         if j == self.F - 1:                     # the batch is complete: one gather
             self._close_batch(slot)
@@ -292,6 +294,7 @@ class SequencePipeline:
             f32 = None if self.f32 is None else (self.f32[slot] if whole else self.f32[slot][j:j + nf])
             launch_seq(u8, f32, nf, self.handles[si])
             self._last = self.u8v[slot][j + nf - 1]
+            self._last32 = self.f32v[slot][j + nf - 1] if self.f32v is not None else None
             self.n += nf
             self.index += nf
             count -= nf
@@ -317,6 +320,9 @@ class SequencePipeline:
 
     def last_slab(self):
         return self._last
+
+    def last_slab_f32(self):
+        return self._last32
 
     def close(self, renderer=None):
         """Before the torch streams go away: let the renderer's context forget their handles (it fences streams that

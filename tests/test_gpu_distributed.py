@@ -79,3 +79,52 @@ def test_bench_exchange_structure_on_one_gpu(extra):
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     j = json.loads(lines[0])
     assert j["frame_matches_reference_sha256"] is True and "gather" in j["config"]["parallelism"]
+
+
+def test_bench_force_gather_float32_assembly():
+    """--gather f32 on a world-size-1 RCCL group: the float32 pre-clip planes travel through their own gather and the
+    assembled frame's hash is still the reference's (the uint8 one); bench.py's line carries the batched-launch fields."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--force-gather", "--gather", "f32", "--warmup", "5", "--steps", "20",
+                          "--no-cpu-baseline", "--no-host-path", "--no-serial", "--no-dynamic"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["frame_matches_reference_sha256"] is True and j["float32_frame_matches_reference_sha256"] is True
+    assert j["frames_per_launch"] > 1 and j["host_submit_ms_per_step"] < 0.05
+
+
+def test_bench_default_line_fields():
+    """The default single-GPU line under the driver's flags: batched launches (host submit cost far below a frame), the
+    moving-camera block, the priced issue bound when the profile constants match this build."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path"],
+                         capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["frame_matches_reference_sha256"] is True and j["config"]["streams"] == 1 and j["frames_per_launch"] >= 4
+    assert j["host_submit_ms_per_step"] <= 0.02
+    d = j["dynamic"]
+    assert d and d["ms_per_step"] > 0 and d["steps"] >= 20
+    assert j["roofline"]["launches_in_flight"] == 1 and abs(j["roofline"]["frac"] - j["roofline"]["per_launch"]["frac"]) < 1e-9
+    if j["valu"]:
+        assert j["valu"]["issue_frac"] <= 1.0 and j["valu"]["issue_bound_ms"] < j["valu"]["issue_estimate_ms"]
+
+
+def test_bench_spawns_its_rank_for_config5_spp4():
+    """`python bench.py --gpus 1 --workload c5_..._spp4` through torch.distributed.run (the launcher the driver uses for
+    N > 1), a few steps of the largest BASELINE configuration: one JSON line with the workload's ray counts."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29548", os.path.join(REPO, "bench.py"),
+                          "--gpus", "1", "--workload", "c5_7680x4320_s256_d8_spp4", "--steps", "4", "--warmup", "1", "--preheat-ms", "0",
+                          "--no-cpu-baseline", "--no-host-path", "--no-serial", "--no-dynamic"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["config"]["workload"] == "c5_7680x4320_s256_d8_spp4" and j["config"]["rays_per_frame"] == 427049977 + 896048151
+    assert j["rays_traced"]["closest_queries"] == 427049977 and 10.0 < j["ms_per_step"] < 200.0

@@ -17,10 +17,10 @@ for step in "$@"; do
     sweep4)   timeout -k 10 300 python tools/depth_sweep.py --workload c4_3840x2160_s64_d5 > $OUT/sweep4.log 2>&1 || exit 1; cat $OUT/sweep4.log ;;
     sweep5)   timeout -k 10 400 python tools/depth_sweep.py --workload c5_7680x4320_s256_d8 --launches 3 > $OUT/sweep5.log 2>&1 || exit 1; cat $OUT/sweep5.log ;;
     prof_c2)  timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c2 --stamp || exit 1 ;;
-    prof_c2s1) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c2_serial --streams 1 --no-pmc || exit 1 ;;
-    prof_c4)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 200 --trace-warmup 10 --pmc-steps 6 --sets sq1,sq2,sq3,sq4 || exit 1 ;;
-    prof_c5)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 30 --trace-warmup 3 --pmc-steps 3 --sets sq1,sq2,sq3,sq4 || exit 1 ;;
-    prof_c5spp4) timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --pmc-steps 2 --sets sq1,sq3 || exit 1 ;;
+    prof_c2s3) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c2_streams3 --streams 3 --no-pmc || exit 1 ;;
+    prof_c4)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 192 --trace-warmup 16 --pmc-steps 32 --sets sq1,sq2,sq3,sq4,fetch,write --stamp || exit 1 ;;
+    prof_c5)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 32 --trace-warmup 4 --pmc-steps 8 --sets sq1,sq2,sq3,sq4,fetch,write --stamp || exit 1 ;;
+    prof_c5spp4) timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --pmc-steps 4 --sets sq1,sq2,sq3,fetch,write --stamp || exit 1 ;;
     trace_c4) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 200 --trace-warmup 10 --no-pmc || exit 1 ;;
     trace_c5) timeout -k 10 300 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 30 --trace-warmup 3 --no-pmc || exit 1 ;;
     trace_c5spp4) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c5spp4 --workload c5_7680x4320_s256_d8_spp4 --trace-steps 12 --trace-warmup 2 --no-pmc || exit 1 ;;
