@@ -272,6 +272,7 @@ def main():
         if world > 1:
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
         n = min(int(cnt[0]), 2_000_000)
+        n = -(-n // F) * F                              # whole launches (a kernel trace of the run then holds launches of one size)
         submit(n)
         pipe.drain()
         preheat_frames = cal + n

@@ -54,8 +54,8 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--streams", type=int, default=1)
-    ap.add_argument("--trace-steps", type=int, default=1000)
-    ap.add_argument("--trace-warmup", type=int, default=50)
+    ap.add_argument("--trace-steps", type=int, default=992)
+    ap.add_argument("--trace-warmup", type=int, default=48)
     ap.add_argument("--pmc-steps", type=int, default=32)
     ap.add_argument("--sets", default="sq1,sq2,sq3,sq4,fetch,write")
     ap.add_argument("--no-pmc", action="store_true")
