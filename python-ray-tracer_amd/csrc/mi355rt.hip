@@ -458,15 +458,25 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const bool settled = feedback && f.have && (same_epoch ? f.builds >= 2 : f.since < ctx->remeasure);
     // A launch of several frames (rt_render_sequence) is ONE launch only in a settled order; until then its frames go
     // through this function one by one (a measuring launch stores the costs of one frame).
-    if (nframes > 1 && (!settled || (long long)grid * nframes >= (1ll << 31))) {
+    auto frame_of = [&](int fr) { rt::KParams kf = k; if (kf.out_u8) kf.out_u8 += (size_t)fr * frame_stride; if (kf.out_f32) kf.out_f32 += (size_t)fr * frame_stride; return kf; };
+    if (nframes > 1 && (long long)grid * nframes >= (1ll << 31)) {            // (a grid beyond 2^31 workgroups: frame by frame)
         for (int fr = 0; fr < nframes; ++fr) {
-            rt::KParams kf = k;
-            if (kf.out_u8) kf.out_u8 += (size_t)fr * frame_stride;
-            if (kf.out_f32) kf.out_f32 += (size_t)fr * frame_stride;
+            rt::KParams kf = frame_of(fr);
             int rc = dispatch(ctx, p, kf, lattice, stream, 1, 0);
             if (rc != RT_OK) return rc;
         }
         return RT_OK;
+    }
+    if (nframes > 1 && feedback && !settled) {
+        // the first frame on its own (it measures, if no measurement is in flight), then — rather than rendering more
+        // frames singly while the order is being built — wait for the build (a fraction of a millisecond, twice per new
+        // geometry) and hand the rest back: at most two single frames before whole batches go out in the settled order
+        rt::KParams kf = frame_of(0);
+        int rc = dispatch(ctx, p, kf, lattice, stream, 1, 0);
+        if (rc != RT_OK) return rc;
+        if (f.building) RT_HIP(ctx, hipEventSynchronize(f.done));
+        rt::KParams kr = frame_of(1);
+        return dispatch(ctx, p, kr, lattice, stream, nframes - 1, frame_stride);
     }
     const bool measure = feedback && !settled && !f.building;  // one measurement in flight at a time (one cost buffer)
     if (settled && !same_epoch) f.since++;
