@@ -433,11 +433,13 @@ def main():
         # region (fence, K steps, fence); never `value`.
         dynamic = None
         if world == 1 and not a.no_dynamic:
-            chunk = 8 * NS                              # frames per call; frame i of a chunk always lands on stream i % NS
+            DNS = 3                                     # one launch per frame: three streams let consecutive frames overlap
+            dstreams = pipe.streams if NS >= DNS else [torch.cuda.Stream(device=dev) for _ in range(DNS)]
+            chunk = 8 * len(dstreams)                   # frames per call; frame i of a chunk always lands on stream i % DNS
             cams = workloads.camera_path(chunk * 16)    # the path repeats; consecutive frames always differ
             dyn8 = torch.empty((chunk, 3, ws, h), dtype=torch.uint8, device=dev)
             dyn32 = torch.empty((chunk, 3, ws, h), dtype=torch.float32, device=dev)
-            handles = tuple(pipe.handles)
+            handles = tuple(st_.cuda_stream for st_ in dstreams)
 
             def dyn(nframes, start=0):
                 done_ = 0
@@ -457,11 +459,14 @@ def main():
             dyn_ms = (time.perf_counter() - td) / dsteps * 1e3
             st = r.stats()
             dynamic = {"ms_per_step": round(dyn_ms, 5), "ratio_to_static": round(dyn_ms / ms_per_step, 4),
-                       "host_submit_ms_per_step": round((td_sub - td) / dsteps * 1e3, 5), "streams": NS, "steps": dsteps,
+                       "host_submit_ms_per_step": round((td_sub - td) / dsteps * 1e3, 5), "streams": len(dstreams), "steps": dsteps,
                        "camera": "python_ray_tracer_amd.workloads.camera_path: position, pitch, yaw and roll change with every frame",
                        "note": "one launch per frame (every frame has its own camera and cull tables); frames bit-equal to the oracle: "
                                "tests/test_gpu_parity.py::test_moving_camera_sequence"}
             r.set_camera(cam.position, cam.rotation)    # back to the static camera for what follows
+            if dstreams is not pipe.streams:
+                for st_ in dstreams:
+                    r.stream_forget(st_.cuda_stream)
             del dyn8, dyn32
 
         # -- the host-buffer entry point (what an unchanged main.py sees: launch + copy_to_host); never `value`
@@ -533,7 +538,10 @@ def main():
         ppath = os.path.join(REPO, "profiles", PRICES)
         if v and os.path.exists(ppath):
             info = r.kernel_info()
-            waves = 7 if (name == workloads.HEADLINE) else 4         # launch bounds of the instantiation the workload selects
+            # launch bounds of the profiled instantiation: the LDS-parked variants (second template argument) are compiled for 7
+            # waves per SIMD, the lane-owned kernels (MODE 2) for 4
+            kn = str(v.get("kernel") or "")
+            waves = 7 if (", true, " in kn.split("<")[-1][:14] and not kn.rstrip(">(rt::KParams)").endswith("2")) else 4
             lo, est, table, col = issue_bound(v, json.load(open(ppath)), waves)
             util = v.get("lane_utilisation") or 1.0
             flop = v["fp64_flop_wave_level_x64"] * util                 # wave-level count x 64 lanes x live-lane fraction
