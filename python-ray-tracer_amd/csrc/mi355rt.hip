@@ -400,7 +400,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // Scheduler feedback (longest-first dispatch): a launch files its tile blocks by cost and dispatches in the
     // order built from the previous measured launch of the same range, depth and AA mode.
     // RT_FLAG_NO_FEEDBACK renders in plain tile order.  Any order renders every tile exactly once.
-    const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 18);
+    const bool feedback = !(p->flags & RT_FLAG_NO_FEEDBACK) && grid > 1 && grid < (1u << 20);
     // XCD-affine block groups (rt::order_kernel): runs of 2^gshift consecutive blocks (neighbours in y, which share 128-byte
     // lines of the output planes) are rendered by ONE XCD, so that its L2 completes those lines before they leave for HBM;
     // inside every XCD the order is block-level longest-first.  Default: groups of 16 tiles.  MI355RT_ORDER_GROUP overrides

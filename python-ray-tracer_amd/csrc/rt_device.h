@@ -938,11 +938,13 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #else
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
+      RT_MARK(1);
       while (mask) {                                          // spheres some live lane might hit, ascending
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
         sphere_closest<F32>(lds, p, k, o, R, a, bestn, bidx);
       }
+      RT_MARK(2);
     }
     double best = 999.0;                                      // trace.py:17
     int idx = -1, type = HIT_NONE;
@@ -1000,12 +1002,14 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
       unsigned long long mask = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
 #endif
       if (LAZY && mask && !haveR) { R = renormalize_unit(d); a = dot3(R, R); a_sane = (a > 0.999999 && a < 1.000001); haveR = true; }
+      RT_MARK(7);
       while (mask) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
         if (!occ) occ = sphere_any<(MODE >= 2)>(lds, k, o, R, a, a_sane);
       }
+      RT_MARK(8);
     }
     const double *pl = lds.recs() + (MODE >= 2 ? 0 : opaque(p.S) * SPH_STRIDE);
     for (int k = 0; k < P; ++k) {
@@ -1673,12 +1677,13 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__
         const int g = b >> gshift;
         const unsigned x = g < full ? gtmp[g] : (unsigned)ORDER_XCDS;
         const int bkt = order_bucket(cost[b]);
-        btmp[b] = (x << 28) | ((unsigned)bkt << 18) | atomicAdd(&hist[x * ORDER_BUCKETS + bkt], 1u);     // nblocks < 2^18 (host)
+        btmp[b] = ((unsigned)bkt << 20) | atomicAdd(&hist[x * ORDER_BUCKETS + bkt], 1u);                  // nblocks < 2^20 (host)
     }
     scan_classes(ORDER_XCDS + 1);
     for (int b = i; b < nblocks; b += ORDER_THREADS) {
-        const unsigned s = btmp[b], x = s >> 28;
-        const unsigned j = hist[x * ORDER_BUCKETS + ((s >> 18) & 1023u)] + (s & 0x3FFFFu);
+        const int g = b >> gshift;
+        const unsigned s = btmp[b], x = g < full ? gtmp[g] : (unsigned)ORDER_XCDS;
+        const unsigned j = hist[x * ORDER_BUCKETS + (s >> 20)] + (s & 0xFFFFFu);
         order[x < (unsigned)ORDER_XCDS ? ORDER_XCDS * j + x : tail + j] = (unsigned)b;
     }
 }

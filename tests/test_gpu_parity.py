@@ -246,8 +246,12 @@ def test_xcd_affine_dispatch_groups(monkeypatch):
     import python_ray_tracer_amd as pkg
     g = load_frame("c2_1080p")
     small = load_frame("odd_37x29")
-    for k in ("1", "4", "6"):
-        monkeypatch.setenv("MI355RT_ORDER_GROUP", k)
+    for k in ("1", "4", "6", "0", None):
+        if k is None:
+            monkeypatch.delenv("MI355RT_ORDER_GROUP", raising=False)
+            monkeypatch.setenv("MI355RT_SEQ_ORDER", "1")       # (tile order also for kernels that default to longest-first)
+        else:
+            monkeypatch.setenv("MI355RT_ORDER_GROUP", k)
         r = pkg.Renderer(0)
         try:
             w, h, _ = _setup(r, g)
@@ -260,12 +264,33 @@ def test_xcd_affine_dispatch_groups(monkeypatch):
                 assert np.array_equal(got, g["frame_u8"]), (k, rep)
             r.free(d8)
             assert r.stats()["launches_settled"] >= 1
+            # the same geometry as a multi-frame launch: all but the last frame run in the XCDs' tile order (the second
+            # permutation order_kernel builds), the last one longest-first — every frame must be the golden frame
+            n = 5
+            dn = r.malloc(n * 3 * w * h)
+            for fpl in (5, 2):
+                r.h2d(dn, np.zeros(n * 3 * w * h, np.uint8))
+                r.render_sequence(p, 0, w, n, dn, None, w * h, 3 * w * h, None, None, fpl)
+                r.sync()
+                got = np.empty((n, 3, w, h), np.uint8); r.d2h(got, dn)
+                for i in range(n):
+                    assert np.array_equal(got[i], g["frame_u8"]), (k, fpl, i)
+            r.free(dn)
             ws, hs, _ = _setup(r, small)
             for rep in range(4):
                 u8, _ = r.render(float(small["amb"]), float(small["lamb"]), float(small["refl"]), int(small["depth"]), int(small["aa"]),
                                  refl_pow=small["refl_pow"])
                 co = small["coords"]
                 assert np.array_equal(u8[:, co[:, 0], co[:, 1]].T, small["u8"]), (k, rep)
+            ps = r.params(float(small["amb"]), float(small["lamb"]), float(small["refl"]), int(small["depth"]), int(small["aa"]), refl_pow=small["refl_pow"])
+            ds = r.malloc(3 * 3 * ws * hs)                     # fewer than eight groups: every block in the order's tail
+            for rep in range(3):
+                r.render_sequence(ps, 0, ws, 3, ds, None, ws * hs, 3 * ws * hs, None, None, 3)
+                r.sync()
+                got = np.empty((3, 3, ws, hs), np.uint8); r.d2h(got, ds)
+                for i in range(3):
+                    assert np.array_equal(got[i][:, co[:, 0], co[:, 1]].T, small["u8"]), (k, rep, i)
+            r.free(ds)
         finally:
             r.close()
 
@@ -606,6 +631,7 @@ def test_repeated_facade_launches_settle(renderer):
     before = r.stats()
     for _ in range(6):
         render[(8, 8), (16, 16)](grid, result, co, cr, sp, li, pl, 0.0, 0.6, 0.3, 3, False)
+        r.sync()          # (a new order is switched to by the first launch that finds its build complete: give each one the chance)
     assert np.array_equal(result.copy_to_host(), g["frame_u8"])
     after = r.stats()
     assert after["launches"] - before["launches"] == 6
