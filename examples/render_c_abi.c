@@ -52,6 +52,28 @@ int main(int argc, char **argv)
     CHECK(ctx, rt_render(ctx, &prm, 0, w, img, NULL));
     rt_kernel_info info;
     CHECK(ctx, rt_get_kernel_info(ctx, &info));
+
+    /* A sequence of frames with ONE call (main.py:41-47 launches frame after frame): five frames into consecutive device
+     * buffers, launches of three frames each, without anti-aliasing; every frame must be the same bytes. */
+    enum { NF = 5 };
+    const size_t fb = (size_t)3 * w * h;
+    void *dseq = NULL;
+    unsigned char *seq = (unsigned char *)malloc(NF * fb);
+    prm.aa_mode = RT_AA_NONE;
+    CHECK(ctx, rt_malloc(ctx, NF * fb, &dseq));
+    for (int rep = 0; rep < 3; ++rep)     /* the first calls measure the tile costs, the last one runs whole batches */
+        CHECK(ctx, rt_render_sequence(ctx, &prm, 0, w, NF, dseq, NULL, (int64_t)w, (int64_t)fb, NULL, NULL, 0, 3));
+    CHECK(ctx, rt_sync(ctx));
+    CHECK(ctx, rt_memcpy_d2h(ctx, seq, dseq, NF * fb));
+    rt_stats st;
+    CHECK(ctx, rt_get_stats(ctx, &st));
+    int same = 1;
+    for (int i = 1; i < NF; ++i) same = same && memcmp(seq, seq + i * fb, fb) == 0;
+    printf("sequence: %d frames %s, %llu launches for %llu frames\n", NF, same ? "identical" : "DIFFER",
+           (unsigned long long)st.launches, (unsigned long long)st.frames);
+    free(seq);
+    CHECK(ctx, rt_free(ctx, dseq));
+    if (!same) return 1;
     CHECK(ctx, rt_destroy(ctx));
 
     const char *path = argc > 1 ? argv[1] : "render_c_abi.ppm";

@@ -824,6 +824,7 @@ def test_c_abi_example_without_python(tmp_path, renderer):
                            "-L", libdir, "-lmi355rt", "-lm", f"-Wl,-rpath,{libdir}", "-o", exe])
     log = subprocess.check_output([exe, out], text=True)
     assert "wrote" in log
+    assert "sequence: 5 frames identical" in log, log          # rt_render_sequence from plain C: batches of 3 + 2 frames
     raw = open(out, "rb").read()
     assert raw.startswith(b"P6\n512 512\n255\n")
     img = np.frombuffer(raw[len(b"P6\n512 512\n255\n"):], np.uint8).reshape(512, 512, 3)
