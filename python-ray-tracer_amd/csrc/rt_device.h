@@ -22,7 +22,8 @@
 //     float64 test can change anything; only spheres some lane might hit get the float64 test.
 //     The cull never decides a hit and never feeds a value into the result — it only skips
 //     float64 evaluations whose outcome (a miss) it has certified with an explicit error margin;
-//   * the kernel is bound by VALU instruction issue (~97 % of it on the headline config) with the CU's single
+//   * the kernel is bound by VALU instruction issue (0.79 of the bound priced with measured cycles per instruction class on the
+//     headline config: float64 4.1-4.2 cycles, 32-bit 2.2, lane masks 4.1-4.2; profiles/r03_valu_prices.json) with the CU's single
 //     scalar ALU as the second bound, so both instruction counts are what the code below economises: lane masks
 //     come straight from compares, the cull's mask is built with s_cmp + s_addc, table entries are one
 //     ds_read_b128 at an immediate offset of a VGPR-pinned base, wave-uniform facts travel in SGPRs;
