@@ -50,7 +50,10 @@ struct rt_ctx {
                                       // frame longest-first; default -1 = tile order for the two-wave kernels (small flat scenes: headline
                                       // 0.1050 ms either way, writes 31.8 instead of 38.7 MB per frame), longest-first for the four-wave ones
                                       // (config 4: 0.734 against 0.785 ms — runs of cheap sky tiles starve the dispatcher in tile order)
-    int lanes_park = 0;               // MI355RT_LANES_PARK=1: LDS-parked variants of the lane-owned kernels (A/B: config 5 8.20 against 7.95 ms)
+    size_t wpw2_max_image = 4608;     // MI355RT_WPW2_MAX_IMAGE: flat scenes whose LDS image is at most this many bytes run two-wave workgroups
+    int order_tiles = 1;              // MI355RT_ORDER_TILES=0: the four-wave kernels' dispatch order per block of four neighbouring tiles (A/B)
+    int lanes_park = 1;               // MI355RT_LANES_PARK=0: register variants of the lane-owned kernels (A/B; with workgroups of equal-cost tiles the
+                                      // parked variants win: config 5 6.88 against 7.16 ms — with neighbouring tiles they lost, 8.20 against 7.95)
     int remeasure = 24;               // MI355RT_REMEASURE: launches a dispatch order measured under an older camera is kept for before
                                       // the tile costs are measured again (a moving camera; any order renders the same frame)
     struct Slot {                     // rt_render_begin / rt_render_end: a frame in flight to host memory
@@ -368,7 +371,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // (Round 2's bundle pre-cull, MODE 1/3, lost against these clusters at every measured size and was removed in round 3:
     // profiles/r02_variant_thresholds.txt.)
     const bool lanes = ctx->NC > 0 && ctx->S >= ctx->lanes_min_spheres && !count && !(p->flags & RT_FLAG_NO_BUNDLES);
-    const int wpw = (image <= 4608 && !count && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
+    const int wpw = (image <= ctx->wpw2_max_image && !count && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const bool ltab = lanes && k.anchors > 0;                     // lane-owned kernels with anchored tables leave the clusters' origin-form spheres out of LDS
     const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, ltab, lanes);
@@ -406,9 +409,14 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     // inside every XCD the order is block-level longest-first.  Default: groups of 16 tiles.  MI355RT_ORDER_GROUP overrides
     // (0 = every block on its own: round 2's order, 1.39x the algorithmic write traffic on the headline frame).
     const int gshift = ctx->order_group >= 0 ? ctx->order_group : (wpw == 2 ? 3 : 2);
+    // Four-wave kernels: the order's items are TILES, not blocks of four neighbouring tiles (rt_device.h: KParams::order_tiles) —
+    // a workgroup's four waves are then tiles of equal cost, end together and free their slots together.
+    const bool otiles = wpw >= RT_TILE_ORDER_MIN_WPW && ctx->order_tiles && feedback;
+    const int wshift = wpw == 4 ? 2 : 1;
+    const unsigned items = otiles ? grid * (unsigned)wpw : grid;          // entries of one permutation
     rt_ctx::Feedback::Key key;
     key.valid = true; key.x0 = x0; key.x1 = x1; key.h = k.h; key.aa = lattice ? 3 : k.aa; key.depth = k.depth;
-    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (lanes ? 32 : 0);
+    key.spp = (k.aa == RT_AA_STOCHASTIC) ? k.spp : 0; key.wpw = wpw + (lanes ? 32 : 0) + (otiles ? 64 : 0);
     rt_ctx::Feedback *fsel = nullptr;
     for (auto &c : ctx->fbs) if (c.key == key) { fsel = &c; break; }
     if (!fsel && feedback) {                                   // a free slot, else the least recently used geometry
@@ -485,7 +493,7 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         if (std::find(f.users.begin(), f.users.end(), stream) == f.users.end()) f.users.push_back(stream);
     }
     if (measure) {
-        const size_t words = (size_t)grid * sizeof(unsigned);
+        const size_t words = (size_t)items * sizeof(unsigned);
         int rc = ensure(ctx, f.cost, words);
         if (rc == RT_OK) rc = ensure(ctx, f.btmp, words);
         if (rc == RT_OK) rc = ensure(ctx, f.order[0], 2 * words);     // longest-first order, then the tile-order one (order_kernel)
@@ -499,7 +507,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         f.fence.clear();
         k.cost = (unsigned *)f.cost.p;
     }
-    k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride; k.seq_offset = (ctx->seq_order < 0 ? wpw == 2 : ctx->seq_order != 0) ? (int)grid : 0;
+    k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride; k.order_tiles = otiles ? 1 : 0;
+    k.seq_offset = (ctx->seq_order < 0 ? wpw == 2 : ctx->seq_order != 0) ? (int)items : 0;
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid * (unsigned)nframes), dim3(wgt), args, lds, stream));
     ctx->stats.launches++;
@@ -508,7 +517,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     if (measure) ctx->stats.launches_measuring++;
     if (measure) {
         hipLaunchKernelGGL(rt::order_kernel, dim3(1), dim3(rt::ORDER_THREADS), 0, stream, (const unsigned *)f.cost.p,
-                           (unsigned *)f.gtmp.p, (unsigned *)f.btmp.p, (unsigned *)f.order[f.cur ^ 1].p, (int)grid, gshift);
+                           (unsigned *)f.gtmp.p, (unsigned *)f.btmp.p, (unsigned *)f.order[f.cur ^ 1].p, (int)items, otiles ? gshift + wshift : gshift,
+                           otiles ? wshift : 0, otiles ? k.ntiles : (int)grid);
         RT_HIP(ctx, hipEventRecord(f.done, stream));
         f.building = true;
         f.build_epoch = ctx->epoch;
@@ -552,6 +562,8 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_REMEASURE")) ctx->remeasure = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("MI355RT_WPW2_MAX_IMAGE")) ctx->wpw2_max_image = (size_t)std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("MI355RT_ORDER_TILES")) ctx->order_tiles = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI355RT_LANES_PARK")) ctx->lanes_park = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI355RT_SEQ_ORDER")) ctx->seq_order = std::atoi(e) != 0 ? 1 : 0;
     if (const char *e = std::getenv("MI355RT_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= RT_RENDER_CHUNKS) ctx->render_chunks = v; }

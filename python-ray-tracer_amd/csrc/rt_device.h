@@ -88,7 +88,10 @@ struct KParams {
     const unsigned *order;     // or nullptr: workgroup -> tile-block permutation from a measured launch's costs (XCD-affine, longest
                                // first inside every XCD); order + bpf: the same XCD assignment in plain tile order, which all but the
                                // last frame of a multi-frame launch use (order_kernel)
-    int seq_offset;            // bpf, or 0 to dispatch every frame of a multi-frame launch longest-first (MI355RT_SEQ_ORDER=0)
+    int order_tiles;           // 1 (four-wave kernels): `order` and `cost` are per TILE — workgroup b's wave w renders tile
+                               // order[b WPW + w], so that a workgroup's waves can be tiles of equal cost (they end together and
+                               // hand their slots back together); 0: per tile block (WPW consecutive tiles)
+    int seq_offset;            // bpf (x WPW with order_tiles), or 0 to dispatch every frame of a multi-frame launch longest-first (MI355RT_SEQ_ORDER=0)
     int nframes, bpf;          // frames rendered by this launch (rt_render_sequence) and workgroups per frame: workgroup b renders
                                // block order[b % bpf] of frame b / bpf into the outputs + (b / bpf) * frame_stride elements
     long long frame_stride;
@@ -1443,8 +1446,16 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
         bid -= frame * p.bpf;
         if (ord && frame < p.nframes - 1) ord += p.seq_offset;
     }
-    const int block = ord ? (int)ord[bid] : bid;
-    const int tile = block * WAVES_PER_WG + wave;
+    // Four-wave kernels may dispatch TILE by tile (p.order_tiles): a workgroup holds its LDS image and — by the time three of its
+    // waves have ended — three idle wave slots until its last wave ends, so its waves should be tiles of EQUAL cost, not
+    // neighbours (measured on config 5: 3.26 of 4 wave slots per SIMD occupied on average with neighbours).
+#ifndef RT_TILE_ORDER_MIN_WPW
+#define RT_TILE_ORDER_MIN_WPW 4
+#endif
+    const bool by_tile = WPW >= RT_TILE_ORDER_MIN_WPW && p.order_tiles;
+    const int block = by_tile ? bid : (ord ? (int)ord[bid] : bid);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int tile = by_tile ? (ord ? (int)ord[bid * WAVES_PER_WG + wave_u] : bid * WAVES_PER_WG + wave_u) : block * WAVES_PER_WG + wave;
     if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
     const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
@@ -1530,12 +1541,15 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     }
     if ((p.tile_cycles || p.cost) && (threadIdx.x & 63) == 0) {               // timing only; never feeds a pixel
         const unsigned cyc = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
-        if (p.tile_cycles) p.tile_cycles[block * WAVES_PER_WG + (threadIdx.x >> 6)] = cyc;
+        if (p.tile_cycles) p.tile_cycles[tile] = cyc;
         if (p.cost) {
-            // the block's cost = sum over its waves; the wave that finishes last stores it
-            const int expected = (p.ntiles - block * WAVES_PER_WG < WAVES_PER_WG) ? p.ntiles - block * WAVES_PER_WG : WAVES_PER_WG;
-            atomicAdd(&wgstat[0], cyc >> 2);
-            if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
+            if (by_tile) p.cost[tile] = cyc >> 2;                             // per tile
+            else {
+                // the block's cost = sum over its waves; the wave that finishes last stores it
+                const int expected = (p.ntiles - block * WAVES_PER_WG < WAVES_PER_WG) ? p.ntiles - block * WAVES_PER_WG : WAVES_PER_WG;
+                atomicAdd(&wgstat[0], cyc >> 2);
+                if ((int)atomicAdd(&wgstat[1], 1u) == expected - 1) p.cost[block] = atomicAdd(&wgstat[0], 0u);
+            }
         }
     }
 }
@@ -1588,9 +1602,19 @@ __global__ __launch_bounds__(256) void aa_resolve_kernel(const KParams p)
 //      measured 37 MB of writes per headline frame instead of 41 for 31 MB of pixels; tile order inside the XCD: see
 //      profiles/r03_order_group_sweep.txt).
 // gtmp: nblocks / 2^gshift + 1 words, btmp: nblocks words of scratch; order: 2 nblocks words.
+// wshift > 0: the items are TILES and a workgroup takes 2^wshift consecutive positions of the order (KParams::order_tiles):
+// XCD x's t-th item then sits at position ((8 (t >> wshift) + x) << wshift) + (t mod 2^wshift) — its (t >> wshift)-th workgroup —
+// and sorting an XCD's tiles by cost makes every workgroup four tiles of (nearly) equal cost.  nvalid: items that exist (the
+// last workgroup's missing tiles cost nothing).  gshift counts items (>= wshift).
 __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__restrict__ cost, unsigned *__restrict__ gtmp,
-                                                               unsigned *__restrict__ btmp, unsigned *__restrict__ order, int nblocks, int gshift)
+                                                               unsigned *__restrict__ btmp, unsigned *__restrict__ order, int nblocks, int gshift,
+                                                               int wshift, int nvalid)
 {
+    const unsigned wm = (1u << wshift) - 1u;
+    auto place = [&](unsigned x, unsigned t, unsigned tail_) -> unsigned {
+        return x < (unsigned)ORDER_XCDS ? ((((unsigned)ORDER_XCDS * (t >> wshift) + x) << wshift) | (t & wm)) : tail_ + t;
+    };
+    auto cost_of = [&](int it) -> unsigned { return it < nvalid ? cost[it] : 0u; };
     __shared__ unsigned hist[(ORDER_XCDS + 1) * ORDER_BUCKETS];     // [class][bucket]; class ORDER_XCDS = the leftover blocks
     __shared__ unsigned scan[ORDER_THREADS / 64];
     static_assert(ORDER_THREADS == ORDER_BUCKETS, "thread i owns bucket 1023 - i");
@@ -1622,7 +1646,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__
     // 1. groups by mean block cost
     for (int g = i; g < full; g += ORDER_THREADS) {
         unsigned long long sum = 0;
-        for (int k = 0; k < gb; ++k) sum += cost[(g << gshift) + k];
+        for (int k = 0; k < gb; ++k) sum += cost_of((g << gshift) + k);
         const unsigned mean = (unsigned)(sum >> gshift);
         const int bkt = order_bucket(mean);
         gtmp[g] = ((unsigned)bkt << 20) | atomicAdd(&hist[bkt], 1u);
@@ -1665,7 +1689,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__
             for (int cc = 0; cc <= ORDER_XCDS; ++cc) if (c == (unsigned)cc) jg = base[cc]++;
             for (int k = 0; k < gb; ++k) {
                 const unsigned j = jg * (unsigned)gb + (unsigned)k;
-                seq[c < (unsigned)ORDER_XCDS ? ORDER_XCDS * j + c : tail + j] = (unsigned)((g << gshift) + k);
+                seq[place(c, j, tail)] = (unsigned)((g << gshift) + k);
             }
         }
         for (int b = (full << gshift) + i; b < nblocks; b += ORDER_THREADS) seq[b] = (unsigned)b;    // the short group: last, in place
@@ -1677,15 +1701,15 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(const unsigned *__
     for (int b = i; b < nblocks; b += ORDER_THREADS) {
         const int g = b >> gshift;
         const unsigned x = g < full ? gtmp[g] : (unsigned)ORDER_XCDS;
-        const int bkt = order_bucket(cost[b]);
-        btmp[b] = ((unsigned)bkt << 20) | atomicAdd(&hist[x * ORDER_BUCKETS + bkt], 1u);                  // nblocks < 2^20 (host)
+        const int bkt = order_bucket(cost_of(b));
+        btmp[b] = ((unsigned)bkt << 22) | atomicAdd(&hist[x * ORDER_BUCKETS + bkt], 1u);                  // items < 2^22 (host)
     }
     scan_classes(ORDER_XCDS + 1);
     for (int b = i; b < nblocks; b += ORDER_THREADS) {
         const int g = b >> gshift;
         const unsigned s = btmp[b], x = g < full ? gtmp[g] : (unsigned)ORDER_XCDS;
-        const unsigned j = hist[x * ORDER_BUCKETS + (s >> 20)] + (s & 0xFFFFFu);
-        order[x < (unsigned)ORDER_XCDS ? ORDER_XCDS * j + x : tail + j] = (unsigned)b;
+        const unsigned j = hist[x * ORDER_BUCKETS + (s >> 22)] + (s & 0x3FFFFFu);
+        order[place(x, j, tail)] = (unsigned)b;
     }
 }
 
