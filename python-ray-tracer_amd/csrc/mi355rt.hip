@@ -50,6 +50,7 @@ struct rt_ctx {
                                       // frame longest-first; default -1 = tile order for the two-wave kernels (small flat scenes: headline
                                       // 0.1050 ms either way, writes 31.8 instead of 38.7 MB per frame), longest-first for the four-wave ones
                                       // (config 4: 0.734 against 0.785 ms — runs of cheap sky tiles starve the dispatcher in tile order)
+    int f32_records = 1;              // MI355RT_F32_RECORDS: four-wave wave-uniform kernels keep no float64 sphere records in LDS (MODE 1)
     size_t wpw2_max_image = 4608;     // MI355RT_WPW2_MAX_IMAGE: flat scenes whose LDS image is at most this many bytes run two-wave workgroups
     int order_tiles = 1;              // MI355RT_ORDER_TILES=0: the four-wave kernels' dispatch order per block of four neighbouring tiles (A/B)
     int lanes_park = 1;               // MI355RT_LANES_PARK=0: register variants of the lane-owned kernels (A/B; with workgroups of equal-cost tiles the
@@ -197,17 +198,20 @@ const void *lanes_variant(bool aa, bool lattice, bool park)
               : (park ? (const void *)rt::render_kernel<false, true, 4, false, false, 2> : (const void *)rt::render_kernel<false, false, 4, false, false, 2>);
 }
 
-const void *lattice_variant(bool park, int wpw, bool count = false)     // the plain kernel over the half-pixel lattice (RT_AA_REFERENCE)
+const void *lattice_variant(bool park, int wpw, bool count = false, bool norec = false)     // the plain kernel over the half-pixel lattice (RT_AA_REFERENCE)
 {
     if (count) return (const void *)rt::render_kernel<false, false, 4, true, true>;
+    if (norec && wpw == 4) return park ? (const void *)rt::render_kernel<false, true, 4, false, true, 1> : (const void *)rt::render_kernel<false, false, 4, false, true, 1>;
     if (wpw == 2) return park ? (const void *)rt::render_kernel<false, true, 2, false, true> : (const void *)rt::render_kernel<false, false, 2, false, true>;
     return park ? (const void *)rt::render_kernel<false, true, 4, false, true> : (const void *)rt::render_kernel<false, false, 4, false, true>;
 }
 
-const void *kernel_variant(bool aa, bool park, int wpw, bool count = false)
+const void *kernel_variant(bool aa, bool park, int wpw, bool count = false, bool norec = false)
 {
     if (count)      // rt_get_stats: the register variant with workgroups of 4 carries the ray counters
         return aa ? (const void *)rt::render_kernel<true, false, 4, true> : (const void *)rt::render_kernel<false, false, 4, true>;
+    if (norec && wpw == 4 && !aa)   // MODE 1: four-wave workgroups without float64 sphere records in LDS (rt_device.h: sphere_hot)
+        return park ? (const void *)rt::render_kernel<false, true, 4, false, false, 1> : (const void *)rt::render_kernel<false, false, 4, false, false, 1>;
     if (wpw == 2)
         return aa ? (park ? (const void *)rt::render_kernel<true, true, 2> : (const void *)rt::render_kernel<true, false, 2>)
                   : (park ? (const void *)rt::render_kernel<false, true, 2> : (const void *)rt::render_kernel<false, false, 2>);
@@ -237,7 +241,7 @@ int acquire_tables(rt_ctx *ctx, const rt::KParams &k, hipStream_t stream, const 
     }
     rt_ctx::Tables &t = *victim;
     t.valid = false;
-    const size_t bytes = rt::table_floats(k.S, k.NC, k.anchors) * sizeof(float);
+    const size_t bytes = rt::table_floats(k.S, k.NC, k.anchors, false, true, k.P) * sizeof(float);   // (with the colours)
     if (t.buf.cap < (bytes ? bytes : 16)) RT_HIP(ctx, hipStreamSynchronize(stream));       // (growing frees the old buffer)
     int rc = ensure(ctx, t.buf, bytes ? bytes : 16);
     if (rc != RT_OK) return rc;
@@ -374,14 +378,29 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
     const int wpw = (image <= ctx->wpw2_max_image && !count && ctx->NC == 0) ? 2 : 4;   // flat scenes only (up to rt::CLUSTER_MIN spheres); measured at 1080p, depth 3 on flat scenes: 2 wins up to 25 spheres (4.1 KB), 4 from 36 (5.4 KB)
     const int wgt = 64 * wpw;
     const bool ltab = lanes && k.anchors > 0;                     // lane-owned kernels with anchored tables leave the clusters' origin-form spheres out of LDS
-    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, ltab, lanes);
+    // MODE 1 (wave-uniform cull, four-wave workgroups, no float64 sphere records in LDS: sphere_hot widens the float32 table
+    // and a hit's colour comes from global memory) where the smaller image lets a CU hold one workgroup more — the parked
+    // variant runs 7 per CU if they fit and needs 6, the register variant 5.  Config 4 (64 spheres): 6 -> 7 workgroups, -5 %;
+    // 100 spheres: register variant at 5 -> parked at 6, -7 %; where the count stays (36, 49, 144 spheres) it costs 0...2 %
+    // (four conversions per sphere test), and the AA kernels lose 1.5 % with it: those keep MODE 0.
+    auto per_cu = [&](bool nr) {
+        const size_t lp = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, ltab, lanes, nr);
+        if (lp * 6 <= 160 * 1024) return (int)std::min<size_t>(7, 160 * 1024 / lp);
+        return (int)std::min<size_t>(5, 160 * 1024 / rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, ltab, lanes, nr));
+    };
+    const bool norec = !lanes && !count && !aa && wpw == 4 && ctx->f32_records && per_cu(true) > per_cu(false);
+    const size_t lds_park = rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, true, wgt, ltab, lanes, norec);
     // (lane-owned kernels are compiled for 4 waves per SIMD = 4 workgroups per CU: parked state while those still fit)
     const bool park = !count && (lanes ? (lds_park * RT_W_LANES <= 160 * 1024 && ctx->lanes_park) : lds_park * (24 / wpw) <= 160 * 1024);
-    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, ltab, lanes);
-    const void *fn = lanes ? lanes_variant(aa, lattice, park) : (lattice ? lattice_variant(park, wpw, count) : kernel_variant(aa, park, wpw, count));
+    const size_t lds = park ? lds_park : rt::lds_bytes(ctx->S, ctx->P, ctx->L, ctx->NC, k.anchors, aa, false, wgt, ltab, lanes, norec);
+    const void *fn = lanes ? lanes_variant(aa, lattice, park) : (lattice ? lattice_variant(park, wpw, count, norec) : kernel_variant(aa, park, wpw, count, norec));
     if (lds > 48 * 1024 && lds > ctx->lds_limit_set) {
         for (int v = 0; v < 8; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, v & 2, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int v = 0; v < 2; ++v) {
+            RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(false, v & 1, 4, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RT_HIP(ctx, hipFuncSetAttribute(lattice_variant(v & 1, 4, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         for (int v = 0; v < 2; ++v)
             RT_HIP(ctx, hipFuncSetAttribute(kernel_variant(v & 1, false, 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int v = 0; v < 4; ++v)
@@ -562,6 +581,7 @@ int rt_create(rt_ctx **out, int device)
     if (const char *e = std::getenv("MI355RT_CHUNK_MODE")) ctx->chunk_mode = std::atoi(e);
     if (const char *e = std::getenv("MI355RT_ORDER_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) ctx->order_group = v; }
     if (const char *e = std::getenv("MI355RT_REMEASURE")) ctx->remeasure = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("MI355RT_F32_RECORDS")) ctx->f32_records = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI355RT_WPW2_MAX_IMAGE")) ctx->wpw2_max_image = (size_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("MI355RT_ORDER_TILES")) ctx->order_tiles = std::atoi(e) != 0;
     if (const char *e = std::getenv("MI355RT_LANES_PARK")) ctx->lanes_park = std::atoi(e) != 0;

@@ -280,6 +280,7 @@ struct Lds {
     const float *cbox;     // NCp x BOX_STRIDE: cluster bounding boxes (rounded outward), for rays without an anchor
     const float *gbox;     // supers(NC) x BOX_STRIDE: boxes around groups of SUPER clusters
     const float *gtab;     // anchors x pad4(supers(NC)) x CULL_STRIDE: the groups' bounding spheres, anchored form
+    const float *col32;    // (Sp + planes) x {R,G,B,-}: colours (MODE 1 kernels only; nullptr otherwise)
     int NC;
     bool groups;           // a compile-time constant per kernel: test a chunk's group of clusters before its clusters (MODE 2 kernels)
 #ifdef RT_REGION_STATS
@@ -911,7 +912,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
-template <int MODE>      // 0: wave-uniform cull; 2: lane-owned traversal of a clustered scene (1 and 3 were round 2's bundle pre-cull, removed)
+template <int MODE>      // 0: wave-uniform cull; 1: the same without float64 sphere records in LDS (sphere_hot); 2: lane-owned traversal of a clustered scene, also without
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
                                             double &t_out, int &idx_out, int &type_out)
 {
@@ -925,7 +926,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
 #endif
     double bestn = __builtin_inf();
     int bidx = -1;
-    constexpr bool F32 = MODE >= 2;                           // sphere records: the float32 LDS table (see sphere_hot)
+    constexpr bool F32 = MODE >= 1;                           // sphere records: the float32 LDS table (see sphere_hot)
     // lane-owned traversal for the rays without a common anchor (bounce 1 on), where the wave's rays have parted;
     // the primary rays of a tile travel together: the wave-uniform cull below is cheaper for them
     if (MODE >= 2 && lds.NC > 0 && (canchor < 0 || p.lanes_primary)) {
@@ -1011,11 +1012,11 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        if (!occ) occ = sphere_any<(MODE >= 2)>(lds, k, o, R, a, a_sane);
+        if (!occ) occ = sphere_any<(MODE >= 1)>(lds, k, o, R, a, a_sane);
       }
       RT_MARK(8);
     }
-    const double *pl = lds.recs() + (MODE >= 2 ? 0 : opaque(p.S) * SPH_STRIDE);
+    const double *pl = lds.recs() + (MODE >= 1 ? 0 : opaque(p.S) * SPH_STRIDE);
     for (int k = 0; k < P; ++k) {
         if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
         if (!occ) {
@@ -1054,38 +1055,44 @@ template <> struct RayCount<true> {
 
 // trace.py:44-112.  On entry `alive` lanes carry a ray (o,d); on exit `alive` is false for lanes
 // that missed (the reference's 404 sentinels), rgb is this bounce's colour, (o,d) the next ray.
-template <bool PARK, int WGT, bool COUNT, bool LANES>
+template <bool PARK, int WGT, bool COUNT, int MODE>
 __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, bool &alive, int anchor,
                                              V3 &o, V3 &d, V3 &rgb, RayCount<COUNT> &cnt)
 {
+    constexpr bool NOREC = MODE >= 1;         // no float64 sphere records in LDS (sphere_hot)
     const int S = p.S, P = p.P, L = opaque(p.L);
     rgb = V3{0.0, 0.0, 0.0};
     double t = 999.0; int idx = -1, type = HIT_NONE;
     cnt.closest(alive);
     RT_MARK(11);
-    if (alive) closest_hit<LANES ? 2 : 0>(lds, p, o, d, anchor, t, idx, type);   // :53 (idle lanes masked off)
+    if (alive) closest_hit<MODE>(lds, p, o, d, anchor, t, idx, type);   // :53 (idle lanes masked off)
     alive = alive && (type != HIT_NONE);                                      // :56-57
     cnt.hit(alive);
     if (alive) {
         V3 Pt{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};                   // :60 (1.0*o is exact)
         // PARK: the object's colour is re-read from its LDS record where it is used (volatile: at the point of
         // use) instead of being held in 6 VGPRs across the shadow queries
-        // LANES kernels keep no float64 sphere records in LDS (sphere_hot): the planes' and lights' records start at 0, and a
+        // MODE 1 / 2 kernels keep no float64 sphere records in LDS (sphere_hot): the planes' and lights' records start at 0, and a
         // hit sphere's colour comes from the packed scene in global memory — through one flat pointer that serves both cases
-        const int plb = LANES ? 0 : opaque(S) * SPH_STRIDE;
+        const int plb = NOREC ? 0 : opaque(S) * SPH_STRIDE;
         const int coff = (type == HIT_SPHERE) ? idx * SPH_STRIDE + 4 : plb + idx * PL_STRIDE + 12;
         volatile const lds_f64 *colp = (volatile const lds_f64 *)lds.recs() + coff;
-        volatile const double *colf = (LANES && type == HIT_SPHERE) ? p.scene + coff : lds.recs() + coff;
+        volatile const double *colf = (NOREC && type == HIT_SPHERE) ? p.scene + coff : lds.recs() + coff;
+        // MODE 1: one float32 LDS table holds the spheres' and the planes' colours (exact: the scene is float32)
+        typedef __attribute__((address_space(3))) float lds_f32;
+        volatile const lds_f32 *col1 = nullptr;
+        if constexpr (MODE == 1) col1 = (volatile const lds_f32 *)lds.col32 + 4 * ((type == HIT_SPHERE) ? idx : (int)padS(S, lds.NC) + idx);
         V3 colr{0.0, 0.0, 0.0};
-        if constexpr (!PARK) colr = V3{colf[0], colf[1], colf[2]};
+        if constexpr (!PARK) colr = (MODE == 1) ? V3{(double)col1[0], (double)col1[1], (double)col1[2]} : V3{colf[0], colf[1], colf[2]};
         auto col = [&](int c) -> double {
-            if constexpr (PARK && LANES) return colf[c];
+            if constexpr (PARK && MODE == 1) return (double)col1[c];
+            else if constexpr (PARK && NOREC) return colf[c];
             else if constexpr (PARK) return colp[c];
             else return c == 0 ? colr.x : (c == 1 ? colr.y : colr.z);
         };
         V3 N, bN;
         if (type == HIT_SPHERE) {                                             // :63-66
-            const SphHot g = sphere_hot<LANES>(lds, idx);
+            const SphHot g = sphere_hot<NOREC>(lds, idx);
             N = normalize3(V3{Pt.x - g.x, Pt.y - g.y, Pt.z - g.z});           // common.py:94-101
             bN = V3{0.0002 * N.x, 0.0002 * N.y, 0.0002 * N.z};
         } else {                                                              // :68-71
@@ -1111,7 +1118,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
             RT_MARK(5);
             if (k > 0.0) {
                 // (the shadow rays of the primary hits still travel together: wave-uniform cull unless p.lanes_primary)
-                const bool occluded = any_hit<LANES ? 2 : 0>(lds, p, Pt, Ld, 1 + m, self, anchor != 0 || p.lanes_primary);
+                const bool occluded = any_hit<MODE>(lds, p, Pt, Ld, 1 + m, self, anchor != 0 || p.lanes_primary);
                 if (!occluded) rgb = V3{rgb.x + k * col(0), rgb.y + k * col(1), rgb.z + k * col(2)};
             }
         }
@@ -1128,7 +1135,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 
 
 // trace.py:115-133.  Bounce 0 rays all start at the camera (cull anchor 0); later bounces have none.
-template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 2 lane-owned traversal
+template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 1 plain without float64 sphere records, 2 lane-owned traversal
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
     Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
@@ -1146,7 +1153,7 @@ __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool aliv
 #ifdef RT_REGION_STATS
         ((volatile unsigned *)lds.reg)[(threadIdx.x >> 6) * 32 + 30] = b >= 2 ? 12u : 0u;
 #endif
-        trace_bounce<PARK, WGT, COUNT, MODE == 2>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
+        trace_bounce<PARK, WGT, COUNT, MODE>(lds, p, alive, b == 0 ? 0 : -1, o, d, rgb, cnt);
         if (b == 0) acc.set(rgb);                                             // :120
         else {                                                                // :131 (a missed bounce adds pow*0)
             const double wgt = p.refl_pow[b - 1];
@@ -1238,11 +1245,13 @@ __host__ __device__ inline size_t lds_doubles(int S, int P, int L) { return (siz
 __host__ __device__ inline int lds_slots(bool aa, bool park, bool mode2 = false) { return park ? ((aa && !mode2) ? 9 : 6) : 0; }   // x workgroup-size doubles (MODE 2: the tap sums stay in registers)
 __host__ __device__ inline int lds_offset_words(bool park, int wgt) { return park ? wgt : 0; }    // + one int32 per thread: the pixel offset
 // The float32 tables of a scene, offsets in floats (every one a multiple of 4):
-//   sph32 | anchored table | cluster anchored table | cluster boxes | group boxes | group anchored table | cluster sph32
+//   sph32 | anchored table | cluster anchored table | cluster boxes | group boxes | group anchored table | cluster sph32 | colours
+// (colours: {R,G,B,-} of the S spheres, padded to Sp entries, then of the P planes — exact, the scene is float32; only
+// the MODE 1 kernels, which keep no float64 sphere records, stage and read them: `total_col` floats instead of `total`)
 // The lane-owned traversal never reads the clusters' origin-form spheres (it tests boxes), so its kernels stage — and
 // reserve LDS for — everything but that last table (`lanes`): config 5's image stays under the 4-workgroups-per-CU line.
-struct TableLayout { size_t tab, ctab, cbox, gbox, gtab, csph32, total_lanes, total; };
-__host__ __device__ inline TableLayout table_layout(int S, int NC, int anchors)
+struct TableLayout { size_t tab, ctab, cbox, gbox, gtab, csph32, total_lanes, total, col32, total_col; };
+__host__ __device__ inline TableLayout table_layout(int S, int NC, int anchors, int P = 0)
 {
     const size_t Sp = padS(S, NC), NCp = pad4(NC), NG = supers(NC), NGp = pad4((int)NG);
     TableLayout t;
@@ -1255,18 +1264,20 @@ __host__ __device__ inline TableLayout table_layout(int S, int NC, int anchors)
     t.total_lanes = o;
     t.csph32 = o; o += 4 * NCp;
     t.total = o;
+    t.col32 = o;  o += 4 * (Sp + (size_t)pad4(P));
+    t.total_col = o;
     return t;
 }
-__host__ __device__ inline size_t table_floats(int S, int NC, int anchors, bool lanes = false)
+__host__ __device__ inline size_t table_floats(int S, int NC, int anchors, bool lanes = false, bool col = false, int P = 0)
 {
-    const TableLayout t = table_layout(S, NC, anchors);
-    return lanes ? t.total_lanes : t.total;
+    const TableLayout t = table_layout(S, NC, anchors, P);
+    return col ? t.total_col : (lanes ? t.total_lanes : t.total);
 }
 // mode2: the kernels of the large clustered scenes (lane-owned traversal) stage no float64 sphere records (sphere_hot)
-__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool lanes = false, bool mode2 = false)
+__host__ __device__ inline size_t lds_bytes(int S, int P, int L, int NC, int anchors, bool aa, bool park, int wgt, bool lanes = false, bool mode2 = false, bool norec = false)
 {
-    return (lds_doubles(mode2 ? 0 : S, P, L) + (size_t)lds_slots(aa, park, mode2) * wgt) * sizeof(double) +
-           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes)) * sizeof(float) + 16   // + workgroup cost/arrival words
+    return (lds_doubles((mode2 || norec) ? 0 : S, P, L) + (size_t)lds_slots(aa, park, mode2) * wgt) * sizeof(double) +
+           ((size_t)lds_offset_words(park, wgt) + table_floats(S, NC, anchors, lanes, norec, P)) * sizeof(float) + 16   // + workgroup cost/arrival words
 #ifdef RT_REGION_STATS
            + (size_t)(wgt / 64) * 32 * sizeof(unsigned)
 #endif
@@ -1281,7 +1292,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
 {
     const int nrec = (int)lds_doubles(p.S, p.P, p.L);
     const int Sp = padS(p.S, p.NC), NCp = pad4(p.NC);
-    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
+    const TableLayout tl = table_layout(p.S, p.NC, p.anchors, p.P);
     float *sph32 = out;
     float *tab = out + tl.tab;                         // anchors x Sp entries
     float *csph32 = out + tl.csph32;
@@ -1293,6 +1304,13 @@ __global__ __launch_bounds__(TABLE_THREADS) void tables_kernel(const KParams p, 
         const bool real = k < p.S;
         sph32[4 * k + 0] = real ? (float)g[0] : 0.0f; sph32[4 * k + 1] = real ? (float)g[1] : 0.0f;
         sph32[4 * k + 2] = real ? (float)g[2] : 0.0f; sph32[4 * k + 3] = real ? (float)g[3] : NINF;
+    }
+    float *col32 = out + tl.col32;
+    for (int k = threadIdx.x; k < Sp + pad4(p.P); k += TABLE_THREADS) {   // colours of spheres and planes (MODE 1 kernels)
+        const double *g = k < p.S ? rec + k * SPH_STRIDE + 4 : rec + p.S * SPH_STRIDE + (k - Sp) * PL_STRIDE + 12;
+        const bool real = k < p.S || (k >= Sp && k - Sp < p.P);
+        for (int c = 0; c < 3; ++c) col32[4 * k + c] = real ? (float)g[c] : 0.0f;
+        col32[4 * k + 3] = 0.0f;
     }
     const double *lt = rec + p.S * SPH_STRIDE + p.P * PL_STRIDE;
     for (int e = threadIdx.x; e < p.anchors * Sp; e += TABLE_THREADS) {
@@ -1393,12 +1411,13 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
 {
     constexpr int WG_THREADS = 64 * WPW, WAVES_PER_WG = WPW;
     constexpr bool M2 = MODE >= 2;
-    const int nrec = (int)lds_doubles(M2 ? 0 : p.S, p.P, p.L);                // MODE 2: planes and lights only (sphere_hot)
-    const double *rec_src = p.scene + (M2 ? (size_t)p.S * SPH_STRIDE : 0);
+    constexpr bool NOREC = MODE >= 1;
+    const int nrec = (int)lds_doubles(NOREC ? 0 : p.S, p.P, p.L);             // MODE 1 / 2: planes and lights only (sphere_hot)
+    const double *rec_src = p.scene + (NOREC ? (size_t)p.S * SPH_STRIDE : 0);
     double *accum = lds_raw + nrec;
     int *offw = reinterpret_cast<int *>(accum + lds_slots(AA, PARK, M2) * WG_THREADS);
     float *sph32 = reinterpret_cast<float *>(offw + lds_offset_words(PARK, WG_THREADS));
-    const TableLayout tl = table_layout(p.S, p.NC, p.anchors);
+    const TableLayout tl = table_layout(p.S, p.NC, p.anchors, p.P);
     // the lane-owned kernels leave the clusters' origin-form spheres in global memory: with anchored tables in place the only
     // rays without an anchor are the reflections, and those test boxes
     const bool LANES = MODE >= 2 && p.anchors > 0;
@@ -1406,13 +1425,14 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     float *csph32 = LANES ? nullptr : sph32 + tl.csph32;
     float *ctab = sph32 + tl.ctab;                     // anchors x NCp entries
     float *cbox = sph32 + tl.cbox;                     // NCp boxes
-    unsigned *wgstat = reinterpret_cast<unsigned *>(sph32 + (LANES ? tl.total_lanes : tl.total));   // {cycles, waves done}
+    const size_t ntab = MODE == 1 ? tl.total_col : (LANES ? tl.total_lanes : tl.total);
+    unsigned *wgstat = reinterpret_cast<unsigned *>(sph32 + ntab);   // {cycles, waves done}
     if (threadIdx.x == 0) { wgstat[0] = 0u; wgstat[1] = 0u; }
     {   // stage the packed scene and its float32 cull tables once per workgroup: two straight copies.  (The tables
         // used to be computed here, by every workgroup: 3 % of the frame's VALU instructions and a second barrier.)
         for (int i = threadIdx.x; i < nrec; i += WG_THREADS) lds_raw[i] = rec_src[i];
 #if RT_PREFILTER
-        const int nf4 = (int)((LANES ? tl.total_lanes : tl.total) / 4);
+        const int nf4 = (int)(ntab / 4);
         const f4 *src = reinterpret_cast<const f4 *>(p.ftab);
         f4 *dst = reinterpret_cast<f4 *>(sph32);
         for (int i = threadIdx.x; i < nf4; i += WG_THREADS) dst[i] = src[i];
@@ -1423,11 +1443,11 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
     // register optimum)
 #ifdef RT_REGION_STATS
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, MODE >= 2, wgstat + 4, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, MODE >= 2, wgstat + 4, accum};
     for (int i = threadIdx.x & 63; i < 32; i += 64) lds.reg[(threadIdx.x >> 6) * 32 + i] = 0u;
     if ((threadIdx.x & 63) == 0) lds.reg[(threadIdx.x >> 6) * 32 + 31] = (unsigned)__builtin_amdgcn_s_memtime();
 #else
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, WPW == 2 ? 0 : p.NC, MODE >= 2, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, MODE >= 2, accum};
 #endif
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

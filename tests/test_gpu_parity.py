@@ -786,6 +786,23 @@ def test_wave_uniform_cull_at_large_scenes(monkeypatch, oracle):
         r.close()
 
 
+@pytest.mark.parametrize("records", ["1", "0"])
+def test_four_wave_kernels_without_float64_records(monkeypatch, oracle, records):
+    """MI355RT_F32_RECORDS (default 1): four-wave wave-uniform kernels stage no float64 sphere records where that lets a CU hold
+    one workgroup more (rt_device.h MODE 1: 64 and 100 spheres take the parked variant, 256 under the wave-uniform cull the
+    register variant; aa=1 on the closed-form grid runs the same kernels over the half-pixel lattice).  Either setting must
+    reproduce the oracle bit for bit."""
+    import python_ray_tracer_amd as pkg
+    monkeypatch.setenv("MI355RT_F32_RECORDS", records)
+    monkeypatch.setenv("MI355RT_LANES_MINS", "100000")
+    r = pkg.Renderer(0)
+    try:
+        for S in (64, 100, 140, 256):
+            _limits_scene_check(r, oracle, S, 3, 1)
+    finally:
+        r.close()
+
+
 def test_max_depth(renderer, oracle):
     g = load_frame("fov70_48")
     w, h, rg = _setup(renderer, g)
