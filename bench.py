@@ -170,7 +170,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # Column slabs: equal widths to start with; with N > 1 the boundaries are then moved until the ranks' MEASURED slab
     # times agree (sky columns are cheap, the sphere cluster is not: equal widths leave the slowest rank 23 % above
@@ -224,7 +224,7 @@ def main():
     # safe key; slices (a partly filled batch) are looked up directly.
     batch_ptrs = {id(t): (t.data_ptr(), f.data_ptr()) for t, f in zip(pipe.u8, pipe.f32)}
     torch_stream = {hnd: st for hnd, st in zip(pipe.handles, pipe.streams)}
-    record = []                                         # (event, stream index, frames) per launch while recording
+    event_pool = []                                     # events whose HIP objects exist already (torch creates them at the first record)
 
     def launch_seq(u8b, f32b, nf, stream):
         p8, p32 = batch_ptrs.get(id(u8b)) or (u8b.data_ptr(), f32b.data_ptr())
@@ -248,7 +248,7 @@ def main():
         while left > 0:                                 # batch by batch, so that every launch gets its event
             room = F - pipe.n % F
             for si, nf in pipe.submit_frames(launch_seq, min(left, room)):
-                ev = torch.cuda.Event(enable_timing=True)
+                ev = event_pool.pop() if event_pool else torch.cuda.Event(enable_timing=True)
                 ev.record(pipe.streams[si])
                 events.append((ev, si, nf))
             left -= min(left, room)
@@ -289,6 +289,10 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     evs = [] if step_events else None
+    if step_events and batched:                         # (creating a HIP event costs microseconds of the 2 ms a --steps 20 run is timed over)
+        event_pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(min(4096, a.steps // F + 2)))
+    for ev in ev0 + ev1 + event_pool:
+        ev.record(pipe.streams[0])
     fence()
     t0 = time.perf_counter()
     for s_ in range(NS):
@@ -297,9 +301,11 @@ def main():
     t_submitted = time.perf_counter()
     for s_ in range(NS):
         ev1[s_].record(pipe.streams[s_])
-    pipe.drain()                                        # every one of the K frames is assembled on its root
+    if world > 1 or use_gather:
+        pipe.drain()                                    # every one of the K frames is assembled on its root
     fence()
     dt = time.perf_counter() - t0
+    gpu_span_ms = max(ev0[s_].elapsed_time(ev1[s_]) for s_ in range(NS))   # first launch's start to the last one's end, device clock
     per_launch, periods, launch_frames = [], [], []
     kernel_ms, frames_per_launch_avg = 0.0, float(F if batched else 1)
     if step_events and evs:
@@ -495,6 +501,7 @@ def main():
             "launch_ms_min": round(min(per_launch), 5) if per_launch else None,
             "preheat_ms": round(preheat_ms, 1), "preheat_frames": preheat_frames,
             "host_submit_ms_per_step": round((t_submitted - t0) / a.steps * 1e3, 5),
+            "gpu_span_ms": round(gpu_span_ms, 4), "timed_region_ms": round(dt * 1e3, 4),   # device clock (first launch's start to the last one's end) / host clock between the fences
             "primary_mrays_per_s": round(w * h / (dt / a.steps) / 1e6, 2),
             "traced_mrays_per_s": round(traced["total_traced"] / (dt / a.steps) / 1e6, 2) if traced else None,
             "rays_traced": traced,

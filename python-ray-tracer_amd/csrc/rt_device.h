@@ -75,7 +75,10 @@ constexpr int CLUSTER_MIN = RT_CLUSTER_MIN;   // scenes with at most this many s
 constexpr int SUPER = 8;           // clusters per group of clusters (one more box each: the lane-owned traversal skips whole groups)
 constexpr int BOX_STRIDE = 8;      // floats per cluster box: lo.xyz, -, hi.xyz, - (two ds_read_b128)
 constexpr int CULL_STRIDE = 4;     // floats per (anchor, sphere) cull entry: Lx,Ly,Lz, tau (one ds_read_b128)
-constexpr int MAX_CULL_TABLE_BYTES = 40 * 1024;   // anchored cull table budget per workgroup (LDS)
+#ifndef RT_MAX_CULL_TABLE_BYTES
+#define RT_MAX_CULL_TABLE_BYTES (40 * 1024)
+#endif
+constexpr int MAX_CULL_TABLE_BYTES = RT_MAX_CULL_TABLE_BYTES;   // anchored cull table budget per workgroup (LDS)
 
 struct KParams {
     const double *scene;       // packed records: S spheres, then P planes, then L lights
