@@ -1478,7 +1478,11 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     const bool by_tile = WPW >= RT_TILE_ORDER_MIN_WPW && p.order_tiles;
     const int block = by_tile ? bid : (ord ? (int)ord[bid] : bid);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int tile = by_tile ? (ord ? (int)ord[bid * WAVES_PER_WG + wave_u] : bid * WAVES_PER_WG + wave_u) : block * WAVES_PER_WG + wave;
+    const int tile_v = by_tile ? (ord ? (int)ord[bid * WAVES_PER_WG + wave_u] : bid * WAVES_PER_WG + wave_u) : block * WAVES_PER_WG + wave;
+    // (wave-uniform, but loaded through a vector register: as a scalar it does not occupy a VGPR until the cost is recorded
+    // at the end — the MODE 1 kernel spilled it, 8 bytes of scratch written per lane; the two-wave kernels keep their register
+    // allocation as it is)
+    const int tile = WPW >= RT_TILE_ORDER_MIN_WPW ? __builtin_amdgcn_readfirstlane(tile_v) : tile_v;
     if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
     const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;

@@ -13,6 +13,10 @@ for step in "$@"; do
     tests)    timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; rc=$?; tail -5 $OUT/tests.log; [ $rc -ne 0 ] && exit $rc ;;
     bench20)  timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench20.json'));print({k:d[k] for k in ('value','ms_per_step','frame_ms_median','frame_ms_min','launch_ms_median','preheat_ms','host_path_ms')}, d['roofline']['serial'], d.get('cpu_baseline'))" ;;
     bench)    timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench.json'));print({k:d[k] for k in ('value','ms_per_step','frame_ms_median','frame_ms_min','launch_ms_median','rays_traced')})" ;;
+    bench_c4|bench_c5|bench_c5spp4)   # the priced bound of the other configs (needs their stamped profiles/valu_r03_*.json of THIS build)
+              case $step in bench_c4) WL=c4_3840x2160_s64_d5; ST=192 ;; bench_c5) WL=c5_7680x4320_s256_d8; ST=32 ;; *) WL=c5_7680x4320_s256_d8_spp4; ST=12 ;; esac
+              timeout -k 10 300 python bench.py --workload $WL --steps $ST --warmup 4 --no-cpu-baseline --no-serial --no-host-path --no-dynamic > $OUT/$step.json 2> $OUT/$step.err || exit 1
+              python -c "import json;d=json.load(open('$OUT/$step.json'));v=d.get('valu') or {};print('$WL', d['ms_per_step'], {k:v.get(k) for k in ('issue_bound_ms','issue_frac','issue_estimate_ms','issue_estimate_frac','salu_bound_ms','lane_utilisation')}, d['roofline'].get('traffic'))" ;;
     bench_noev) timeout -k 10 300 python bench.py --no-cpu-baseline --no-step-events --no-serial --no-host-path > $OUT/bench_noev.json 2> $OUT/bench_noev.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench_noev.json'));print(d['ms_per_step'])" ;;
     sweep4)   timeout -k 10 300 python tools/depth_sweep.py --workload c4_3840x2160_s64_d5 > $OUT/sweep4.log 2>&1 || exit 1; cat $OUT/sweep4.log ;;
     sweep5)   timeout -k 10 400 python tools/depth_sweep.py --workload c5_7680x4320_s256_d8 --launches 3 > $OUT/sweep5.log 2>&1 || exit 1; cat $OUT/sweep5.log ;;
