@@ -194,7 +194,7 @@ int check_params(rt_ctx *ctx, const rt_params *p, int x0, int x1)
 const void *lanes_variant(bool aa, bool lattice, bool park)
 {
     if (lattice) return park ? (const void *)rt::render_kernel<false, true, 4, false, true, 2> : (const void *)rt::render_kernel<false, false, 4, false, true, 2>;
-    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4, false, false, 2> : (const void *)rt::render_kernel<true, false, 4, false, false, 2>)
+    return aa ? (park ? (const void *)rt::render_kernel<true, true, 4, false, false, 3> : (const void *)rt::render_kernel<true, false, 4, false, false, 2>)
               : (park ? (const void *)rt::render_kernel<false, true, 4, false, false, 2> : (const void *)rt::render_kernel<false, false, 4, false, false, 2>);
 }
 

@@ -221,18 +221,32 @@ enum { HIT_NONE = 0, HIT_SPHERE = 1, HIT_PLANE = 2 };
 // are forwarded and the values stay in VGPRs; without the address space the accesses become flat).
 // Scenes whose LDS image is too large for 6+ workgroups per CU run the register variant (host picks).
 typedef __attribute__((address_space(3))) double lds_f64;
-template <bool PARK, int WGT> struct Park3 {
+// REMAT (MODE 3 = MODE 2 with this; the AA kernels of the large clustered scenes, which run at 128 VGPRs with the most spills,
+// take it: config 5 at 4 spp -1.5 %, while the 1 spp kernels lose 0.3 % with it): the slot's address is not kept in a
+// register between accesses but re-derived at each one from the wave's index (a scalar) and the lane's number (two v_mbcnt,
+// volatile so that the compiler does not hoist and keep them): three instructions per access, one VGPR less across the whole
+// bounce.
+__device__ __forceinline__ unsigned fresh_lane()
+{
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+template <bool PARK, int WGT, bool REMAT = false> struct Park3 {
     volatile lds_f64 *p;
+    volatile lds_f64 *sbase;       // REMAT: the slot's first word of this wave (scalar)
     V3 v;
-    __device__ __forceinline__ Park3(double *base, int slot)
-        : p((volatile lds_f64 *)base + slot * 3 * WGT + threadIdx.x), v{0.0, 0.0, 0.0} {}
+    __device__ __forceinline__ Park3(double *base, int slot, int wave = 0)
+        : p(REMAT ? nullptr : (volatile lds_f64 *)base + slot * 3 * WGT + threadIdx.x),
+          sbase(REMAT ? (volatile lds_f64 *)base + slot * 3 * WGT + wave * 64 : nullptr), v{0.0, 0.0, 0.0} {}
+    __device__ __forceinline__ volatile lds_f64 *at() const { if constexpr (REMAT) return sbase + fresh_lane(); else return p; }
     __device__ __forceinline__ void set(const V3 &a)
     {
-        if constexpr (PARK) { p[0] = a.x; p[WGT] = a.y; p[2 * WGT] = a.z; } else v = a;
+        if constexpr (PARK) { volatile lds_f64 *q = at(); q[0] = a.x; q[WGT] = a.y; q[2 * WGT] = a.z; } else v = a;
     }
     __device__ __forceinline__ V3 get() const
     {
-        if constexpr (PARK) return V3{p[0], p[WGT], p[2 * WGT]}; else return v;
+        if constexpr (PARK) { volatile lds_f64 *q = at(); return V3{q[0], q[WGT], q[2 * WGT]}; } else return v;
     }
 };
 
@@ -285,6 +299,7 @@ struct Lds {
     const float *gtab;     // anchors x pad4(supers(NC)) x CULL_STRIDE: the groups' bounding spheres, anchored form
     const float *col32;    // (Sp + planes) x {R,G,B,-}: colours (MODE 1 kernels only; nullptr otherwise)
     int NC;
+    int wave;              // this wave's index in its workgroup (scalar)
     bool groups;           // a compile-time constant per kernel: test a chunk's group of clusters before its clusters (MODE 2 kernels)
 #ifdef RT_REGION_STATS
     unsigned *reg;         // measurement build: 32 words per wave — cycles per code region [0, 24), bounce class [30], last stamp [31]
@@ -915,7 +930,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
 // trace.py:7-41, closest hit.  R = normalize(d) and a = R.R are computed once per query.
 // anchor: index into the cull table of a point every live lane's ray passes through (0 = camera),
 // or -1 for rays with no common anchor (reflections).
-template <int MODE>      // 0: wave-uniform cull; 1: the same without float64 sphere records in LDS (sphere_hot); 2: lane-owned traversal of a clustered scene, also without
+template <int MODE>      // 0: wave-uniform cull; 1: the same without float64 sphere records in LDS (sphere_hot); 2: lane-owned traversal of a clustered scene, also without; 3: 2 with re-derived park addresses (Park3)
 __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, const V3 &o, const V3 &d, int anchor,
                                             double &t_out, int &idx_out, int &type_out)
 {
@@ -1106,7 +1121,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
         rgb = V3{p.amb * col(0), p.amb * col(1), p.amb * col(2)};             // :77 (0 + amb*col)
         Pt = V3{Pt.x + bN.x, Pt.y + bN.y, Pt.z + bN.z};                       // :82-83
         const int self = (type == HIT_SPHERE) ? idx : -1;
-        Park3<PARK, WGT> dpark(lds.acc, 1);      // the incoming direction is only needed again for the reflection
+        Park3<PARK, WGT, MODE == 3> dpark(lds.acc, 1, lds.wave);      // the incoming direction is only needed again for the reflection
         dpark.set(d);
         RT_MARK(4);
 
@@ -1141,7 +1156,7 @@ __device__ __forceinline__ void trace_bounce(const Lds &lds, const KParams &p, b
 template <bool PARK, int WGT, bool COUNT, int MODE>       // MODE: 0 plain, 1 plain without float64 sphere records, 2 lane-owned traversal
 __device__ __forceinline__ V3 sample(const Lds &lds, const KParams &p, bool alive, V3 o, V3 d, RayCount<COUNT> &cnt)
 {
-    Park3<PARK, WGT> acc(lds.acc, 0);                                              // the running colour
+    Park3<PARK, WGT, MODE == 3> acc(lds.acc, 0, lds.wave);           // the running colour
     acc.set(V3{0.0, 0.0, 0.0});
     for (int b = 0; b <= p.depth; ++b) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;                                   // wave-uniform exit
@@ -1446,11 +1461,11 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
     // register optimum)
 #ifdef RT_REGION_STATS
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, MODE >= 2, wgstat + 4, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), MODE >= 2, wgstat + 4, accum};
     for (int i = threadIdx.x & 63; i < 32; i += 64) lds.reg[(threadIdx.x >> 6) * 32 + i] = 0u;
     if ((threadIdx.x & 63) == 0) lds.reg[(threadIdx.x >> 6) * 32 + 31] = (unsigned)__builtin_amdgcn_s_memtime();
 #else
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, MODE >= 2, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), MODE >= 2, accum};
 #endif
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1495,8 +1510,10 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // PARK: the pixel's output offset waits in LDS instead of staying live (or being spilled to scratch)
     // across the whole trace; -1 marks lanes outside the frame.
     typedef __attribute__((address_space(3))) int lds_i32;
-    volatile lds_i32 *offp = (volatile lds_i32 *)offw + threadIdx.x;
-    if constexpr (PARK) *offp = inb ? (x - p.x0) * p.h + y : -1;              // w*h <= 2^31 (checked by the host)
+    // (REMAT kernels re-derive it at the end from the tile, a scalar, and the lane's number instead: see Park3)
+    constexpr bool OFF_REMAT = PARK && MODE == 3;
+    volatile lds_i32 *offp = OFF_REMAT ? nullptr : (volatile lds_i32 *)offw + threadIdx.x;
+    if constexpr (PARK && !OFF_REMAT) *offp = inb ? (x - p.x0) * p.h + y : -1;   // w*h <= 2^31 (checked by the host)
 
     const V3 o{p.cam_o[0], p.cam_o[1], p.cam_o[2]};                           // kernels.py:16
     RayCount<COUNT> cnt;
@@ -1541,7 +1558,13 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     }
 
     long long off;
-    if constexpr (PARK) off = *offp; else off = inb ? (long long)(x - p.x0) * p.h + y : -1ll;   // (int32 -1 sign-extends)
+    if constexpr (OFF_REMAT) {
+        const int l2 = (int)fresh_lane();
+        const int x2 = p.x0 + tx * TILE + (l2 >> 3), y2 = ty * TILE + (l2 & 7);
+        bool inb2 = (x2 < p.x1) && (y2 < p.h);
+        if constexpr (LAT) inb2 = inb2 && ((((x2 | y2) & 1) == 0) || (x2 >= 1 && x2 <= p.w - 2 && y2 >= 1 && y2 <= p.h - 2));
+        off = inb2 ? (long long)((x2 - p.x0) * p.h + y2) : -1ll;
+    } else if constexpr (PARK) off = *offp; else off = inb ? (long long)(x - p.x0) * p.h + y : -1ll;   // (int32 -1 sign-extends)
     if (off >= 0) {
         if constexpr (LAT) {                                                  // one float64 (R,G,B) per lattice sample
             double *q = p.out_f64 + off * 3;

@@ -17,6 +17,7 @@ for step in "$@"; do
               case $step in bench_c4) WL=c4_3840x2160_s64_d5; ST=192 ;; bench_c5) WL=c5_7680x4320_s256_d8; ST=32 ;; *) WL=c5_7680x4320_s256_d8_spp4; ST=12 ;; esac
               timeout -k 10 300 python bench.py --workload $WL --steps $ST --warmup 4 --no-cpu-baseline --no-serial --no-host-path --no-dynamic > $OUT/$step.json 2> $OUT/$step.err || exit 1
               python -c "import json;d=json.load(open('$OUT/$step.json'));v=d.get('valu') or {};print('$WL', d['ms_per_step'], {k:v.get(k) for k in ('issue_bound_ms','issue_frac','issue_estimate_ms','issue_estimate_frac','salu_bound_ms','lane_utilisation')}, d['roofline'].get('traffic'))" ;;
+    collect)  bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1 || exit 1; tail -2 $OUT/collect.log ;;   # this session's stamps into the box's profiles/ (for the bench_* steps after it)
     bench_noev) timeout -k 10 300 python bench.py --no-cpu-baseline --no-step-events --no-serial --no-host-path > $OUT/bench_noev.json 2> $OUT/bench_noev.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench_noev.json'));print(d['ms_per_step'])" ;;
     sweep4)   timeout -k 10 300 python tools/depth_sweep.py --workload c4_3840x2160_s64_d5 > $OUT/sweep4.log 2>&1 || exit 1; cat $OUT/sweep4.log ;;
     sweep5)   timeout -k 10 400 python tools/depth_sweep.py --workload c5_7680x4320_s256_d8 --launches 3 > $OUT/sweep5.log 2>&1 || exit 1; cat $OUT/sweep5.log ;;
