@@ -37,10 +37,14 @@
 // Build-time knobs (A/B builds for tools/ab_bench.py); the defaults are the measured best on MI355X:
 //   RT_PREFILTER        float32 cull in front of the float64 sphere tests            (C2 -23 %, C4 -63 %)
 //   RT_FAST_NORMALIZE   shared-reciprocal normalize instead of sqrt + three divisions (C2 -10 %)
+//   RT_FAST_DIVSQRT     0 = the backend's full f64 division / sqrt in the scene queries (div_inrange, sqrt_inrange)
 //   RT_CLUSTER_MIN      sphere count above which the scene is stored in clusters of 8
 //   RT_W_PARK, RT_W_AAPARK  waves/SIMD the LDS-parked variants are compiled for
 #ifndef RT_PREFILTER
 #define RT_PREFILTER 1
+#endif
+#ifndef RT_FAST_DIVSQRT
+#define RT_FAST_DIVSQRT 1
 #endif
 #ifndef RT_FAST_NORMALIZE
 #define RT_FAST_NORMALIZE 1
@@ -171,6 +175,42 @@ __device__ __forceinline__ V3 normalize3(const V3 &v)
     return V3{__builtin_fma(__builtin_fma(-g, qx, v.x), rc, qx),
               __builtin_fma(__builtin_fma(-g, qy, v.y), rc, qy),
               __builtin_fma(__builtin_fma(-g, qz, v.z), rc, qz)};
+#endif
+}
+
+// The scene queries' own division and square root (t = num/den of a plane, t = n/a of the closest sphere, sqrt of a sphere's
+// discriminant), as the backend lowers them minus the range handling (see normalize3 above): v_div_scale x2 / v_div_fixup
+// and the sqrt's ldexp scaling are identities for operands well inside the exponent range, and there they are: scene values
+// are float32 (magnitudes 2^-149 .. 2^128 or zero), a plane's denominator is at least 0.001 in magnitude where the quotient is
+// formed (intersections.py:55), a is within rounding of 1, numerators and discriminants are sums of a few products of such
+// values (zero, or above 2^-600), while the backend scales below 2^-767 (sqrt) / numerators below 2^-969, denominators of
+// extreme exponent, exponent differences beyond 2^768 (division).  Outside that range (a camera at 1e300, infinities) both
+// forms end in an infinity, a NaN or a value whose comparison with (0, 999) has the same outcome: no hit.  3 of 11
+// instructions per division, 7 of 21 per square root.  tests/algo/divsqrt_check.c replays both on the CPU.
+__device__ __forceinline__ double div_inrange(double a, double b)
+{
+#if RT_FAST_DIVSQRT == 0
+    return a / b;
+#else
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#endif
+}
+__device__ __forceinline__ double sqrt_inrange(double x)      // x >= 0 (or NaN)
+{
+#if RT_FAST_DIVSQRT == 0
+    return __builtin_sqrt(x);
+#else
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : x;                                   // sqrt(+0) = +0 (the iteration yields NaN there: 0 * inf)
 #endif
 }
 
@@ -682,7 +722,7 @@ __device__ __forceinline__ void sphere_closest(const Lds &lds, const KParams &p,
     const double cc = dot3(Lv, Lv) - g.r2;                    // :21 (r2 = float32 r*r, widened)
     const double D = s * s - a * cc;                          // disc/4
     if (D >= 0.0 && !(s >= 0.0 && cc >= 0.0)) {
-        const double q = __builtin_sqrt(D);
+        const double q = sqrt_inrange(D);
         double n = -s - q;                                    // :28
         if (!(n > 0.0)) n = -s + q;                           // :33
         // The reference compares the rounded quotients t = n/a with a strict `best > t`, in ascending caller
@@ -699,7 +739,7 @@ __device__ __forceinline__ void sphere_closest(const Lds &lds, const KParams &p,
             const bool close = __builtin_fabs(n - bestn) < bestn * 0x1p-50;   // false while bestn = +inf (bidx = -1)
             if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
                 if (close) {
-                    const double tq = n / a, tb = bestn / a;                  // :31 / :36
+                    const double tq = div_inrange(n, a), tb = div_inrange(bestn, a);   // :31 / :36
                     take = tq < tb || (tq == tb && sphere_orig<F32>(lds, p, k) < sphere_orig<F32>(lds, p, bidx));
                 }
             }
@@ -722,11 +762,11 @@ __device__ __forceinline__ bool sphere_any(const Lds &lds, int k, const V3 &o, c
         // the reference's t is at most n2/a.  n2 <= 998 (from -s < 499, q <= 499) and a within
         // 1e-6 of 1 give t < 999: occluded, decided without sqrt or divide.
         if (s < 0.0 && -s < 499.0 && D < 249001.0 && a_sane) return true;
-        const double q = __builtin_sqrt(D);                   // origin inside the sphere, or a far hit: exact path
+        const double q = sqrt_inrange(D);                     // origin inside the sphere, or a far hit: exact path
         double n = -s - q;
         if (!(n > 0.0)) n = -s + q;
         if (n > 0.0) {
-            const double t = n / a;
+            const double t = div_inrange(n, a);
             if (999.0 > t && t > 0.0) return true;
         }
     }
@@ -972,7 +1012,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
     double best = 999.0;                                      // trace.py:17
     int idx = -1, type = HIT_NONE;
     if (bidx >= 0) {
-        const double t = bestn / a;                           // :31 / :36, once per query
+        const double t = div_inrange(bestn, a);               // :31 / :36, once per query
         if (best > t && t > 0.0) { best = t; idx = bidx; type = HIT_SPHERE; }
     }
     const double *pl = lds.recs() + (F32 ? 0 : opaque(p.S) * SPH_STRIDE);
@@ -981,7 +1021,7 @@ __device__ __forceinline__ void closest_hit(const Lds &lds, const KParams &p, co
         double den, num;
         plane_den_num(g, plane_code(p, k), o, d, den, num);   // :52, :59-61
         if (!(__builtin_fabs(den) < 0.001)) {                 // :55
-            const double t = num / den;                       // :63
+            const double t = div_inrange(num, den);           // :63
             if (best > t && t > 0.0) { best = t; idx = k; type = HIT_PLANE; }
         }
     }

@@ -25,6 +25,13 @@ def test_shared_reciprocal_normalize_is_bit_identical(tmp_path):
     assert "mismatches=0" in out and "sqrt_mismatches=0" in out, out
 
 
+def test_in_range_division_and_sqrt_are_bit_identical(tmp_path):
+    """rt_device.h div_inrange / sqrt_inrange (the scene queries' t = num/den, t = n/a, sqrt(D)): the backend's sequences
+    without their range handling, over operand ranges wider than float32 scenes produce."""
+    out = subprocess.check_output([_build("divsqrt_check", tmp_path), "20000000"], text=True)
+    assert "div_mismatches=0" in out and "sqrt_mismatches=0" in out, out
+
+
 def test_oracle_under_asan_ubsan(tmp_path):
     """the CPU restatement under AddressSanitizer + UndefinedBehaviorSanitizer (the GPU side cannot run
     sanitizers on this pool).  Two scenes (a golden's, and an empty one) through every oracle entry point; the
