@@ -113,6 +113,57 @@ def stamped(path, so_sha):
     return d if d.get("so_sha256") == so_sha else None
 
 
+class HostStagedGroup:
+    """REHEARSAL ONLY (--rehearse-gloo): the torch.distributed calls this file and SequencePipeline make, on the gloo backend
+    with every device tensor staged through host memory.  RCCL refuses two ranks on one device, so this is the only way to run
+    the N > 1 control flow (slab balancing, batched gathers with a rotating root, per-rank statistics) on a one-GPU box: N
+    processes share cuda:0.  The frames are checked like any other run's; the timings mean nothing."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self, dist, torch):
+        self.d, self.torch, self.ReduceOp = dist, torch, dist.ReduceOp
+
+    def get_rank(self):
+        return self.d.get_rank()
+
+    def get_world_size(self):
+        return self.d.get_world_size()
+
+    def barrier(self):
+        self.d.barrier()
+
+    def destroy_process_group(self):
+        self.d.destroy_process_group()
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def broadcast(self, t, src=0):
+        c = t.cpu()
+        self.d.broadcast(c, src=src)
+        t.copy_(c)
+
+    def all_gather(self, outs, t):
+        cs = [self.torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        self.d.all_gather(cs, t.cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
+    def gather(self, t, recv, dst=0, async_op=False):
+        c = t.cpu()                                     # (on the current stream, behind whatever it waits for; then the host waits)
+        rc = [self.torch.empty(c.shape, dtype=c.dtype) for _ in recv] if recv is not None else None
+        self.d.gather(c, rc, dst=dst)
+        if recv is not None:
+            for o, x in zip(recv, rc):
+                o.copy_(x)
+        return self._Done()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +183,8 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point rt_render (host_path_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for every launch (e.g. 4 = RT_FLAG_NO_FEEDBACK; profiling variants)")
+    ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 on ONE GPU: all ranks share cuda:0, collectives on gloo through host copies "
+                    "(HostStagedGroup): checks the control flow and the assembled frames, its timings mean nothing")
     ap.add_argument("--gather-root", choices=("rotate", "fixed"), default="rotate",
                     help="N > 1: assemble batch b on rank b %% N (every rank's links carry a share of the exchange) or always on rank 0")
     ap.add_argument("--balance-rounds", type=int, default=4, help="N > 1: rounds of measured-time slab balancing before the run (0 = equal-width slabs)")
@@ -152,10 +205,16 @@ def main():
     from python_ray_tracer_amd import workloads, _lib
     from python_ray_tracer_amd.distributed import slab_bounds, SequencePipeline
 
+    if a.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse_gloo:
+            dist.init_process_group("gloo")
+            dist = HostStagedGroup(dist, torch)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     name = a.workload or workloads.HEADLINE
     wl = workloads.build(name)
@@ -484,6 +543,7 @@ def main():
             "metric": "Mrays/sec + frame time (ms) at 1920x1080, 8 spheres, depth=3",
             "value": round(rays_per_frame / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
+            "rehearsal": "all ranks on one GPU, collectives on gloo through host copies: the timings are NOT measurements" if a.rehearse_gloo else None,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "width": w, "height": h, "spheres": S, "planes": P, "lights": L,
                        "depth": wl["depth"], "aa": bool(wl["aa"]), "rays_per_frame": rays_per_frame,

@@ -128,3 +128,28 @@ def test_bench_spawns_its_rank_for_config5_spp4():
     j = json.loads(lines[0])
     assert j["config"]["workload"] == "c5_7680x4320_s256_d8_spp4" and j["config"]["rays_per_frame"] == 427049977 + 896048151
     assert j["rays_traced"]["closest_queries"] == 427049977 and 10.0 < j["ms_per_step"] < 200.0
+
+
+@pytest.mark.parametrize("n,extra", [(2, ["--gather", "f32"]), (3, ["--gather-root", "fixed", "--frames-per-gather", "4"])])
+def test_bench_multi_rank_rehearsal_on_one_gpu(n, extra):
+    """bench.py's N > 1 control flow — slab balancing from measured times, batches of frames gathered to a rotating (or fixed)
+    root, float32 assembly, per-rank statistics — with N processes sharing this box's one GPU (--rehearse-gloo: RCCL refuses two
+    ranks on a device, so the collectives run on gloo through host copies).  The assembled frame of the last batch must be the
+    reference's; every rank must appear in the line.  Timings of such a run are not measurements and are not checked."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29560 + n), os.path.join(REPO, "bench.py"),
+                          "--gpus", str(n), "--rehearse-gloo", "--steps", "24", "--warmup", "4", "--preheat-ms", "20", "--balance-rounds", "2",
+                          "--no-cpu-baseline", "--no-serial", "--no-dynamic"] + extra,
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == n and j["rehearsal"] and j["frame_matches_reference_sha256"] is True
+    if "f32" in extra:
+        assert j["float32_frame_matches_reference_sha256"] is True
+    assert len(j["per_rank"]) == n and [q["rank"] for q in j["per_rank"]] == list(range(n))
+    cols = [q["columns"] for q in j["per_rank"]]
+    assert cols[0][0] == 0 and cols[-1][1] == j["config"]["width"] and all(cols[i][1] == cols[i + 1][0] for i in range(n - 1))
+    assert j["slab_balance"]["rounds"] == 2 and len(j["slab_balance"]["chosen"]["slab_ms"]) == n
