@@ -21,7 +21,7 @@ for step in "$@"; do
     bench_noev) timeout -k 10 300 python bench.py --no-cpu-baseline --no-step-events --no-serial --no-host-path > $OUT/bench_noev.json 2> $OUT/bench_noev.err || exit 1; python -c "import json;d=json.load(open('$OUT/bench_noev.json'));print(d['ms_per_step'])" ;;
     sweep4)   timeout -k 10 300 python tools/depth_sweep.py --workload c4_3840x2160_s64_d5 > $OUT/sweep4.log 2>&1 || exit 1; cat $OUT/sweep4.log ;;
     sweep5)   timeout -k 10 400 python tools/depth_sweep.py --workload c5_7680x4320_s256_d8 --launches 3 > $OUT/sweep5.log 2>&1 || exit 1; cat $OUT/sweep5.log ;;
-    prof_c2)  timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c2 --stamp || exit 1 ;;
+    prof_c2)  timeout -k 10 900 python tools/profile_round.py --tag ${TAG}_c2 --pmc-steps 320 --stamp || exit 1 ;;   # (320 steps: the counters' per-frame means then weigh the 16-frame launches as a real run does, not the two single measuring frames)
     prof_c2s3) timeout -k 10 400 python tools/profile_round.py --tag ${TAG}_c2_streams3 --streams 3 --no-pmc || exit 1 ;;
     prof_c4)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c4 --workload c4_3840x2160_s64_d5 --trace-steps 192 --trace-warmup 16 --pmc-steps 32 --sets sq1,sq2,sq3,sq4,fetch,write --stamp || exit 1 ;;
     prof_c5)  timeout -k 10 600 python tools/profile_round.py --tag ${TAG}_c5 --workload c5_7680x4320_s256_d8 --trace-steps 32 --trace-warmup 4 --pmc-steps 8 --sets sq1,sq2,sq3,sq4,fetch,write --stamp || exit 1 ;;
