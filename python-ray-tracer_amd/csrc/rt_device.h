@@ -46,6 +46,9 @@
 #ifndef RT_FAST_DIVSQRT
 #define RT_FAST_DIVSQRT 1
 #endif
+#ifndef RT_SHADOW_EXIT_CHECKS
+#define RT_SHADOW_EXIT_CHECKS 0
+#endif
 #ifndef RT_FAST_NORMALIZE
 #define RT_FAST_NORMALIZE 1
 #endif
@@ -930,7 +933,7 @@ __device__ __forceinline__ bool lanes_any(const Lds &lds, const KParams &p, int 
     } else add_origin(q, o, p.extent2);
     bool occ = false;
     for (int cb = 0; cb < lds.NC; cb += 32) {
-        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
+        if ((RT_SHADOW_EXIT_CHECKS || cb > 0) && __builtin_amdgcn_ballot_w64(!occ) == 0ull) break;   // (nothing is occluded before the first block)
         const int nc = lds.NC - cb < 32 ? lds.NC - cb : 32;
         unsigned cm = lane_cluster_bits<ANCH>(lds, anchor, cb, nc, q, p.extent2);
         RT_MARK(7);
@@ -1055,7 +1058,10 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
         occ = (canchor >= 0) ? lanes_any<true>(lds, p, canchor, o, R, a, self) : lanes_any<false>(lds, p, -1, o, R, a, self);
     } else
     for (int k0 = 0; k0 < S; k0 += 64) {
-      if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
+      // "is any live lane still unoccluded" compiles to a v_cndmask + v_cmp pair (the bool lives as a lane mask that may hold
+      // stale bits of inactive lanes): asked only where the answer can be no and skipping pays — not before the first chunk,
+      // not before the first sphere of the first chunk, not before a plane (RT_SHADOW_EXIT_CHECKS = 1: everywhere, as before)
+      if ((RT_SHADOW_EXIT_CHECKS || k0 > 0) && __builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
       const int n = (S - k0 < 64) ? S - k0 : 64;
 #if RT_PREFILTER
       unsigned long long mask;
@@ -1067,16 +1073,17 @@ __device__ __forceinline__ bool any_hit(const Lds &lds, const KParams &p, const 
       if (LAZY && mask && !haveR) { R = renormalize_unit(d); a = dot3(R, R); a_sane = (a > 0.999999 && a < 1.000001); haveR = true; }
       RT_MARK(7);
       while (mask) {
-        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;                    // every live lane already occluded
+        if (RT_SHADOW_EXIT_CHECKS && __builtin_amdgcn_ballot_w64(!occ) == 0ull) break;   // every live lane already occluded
         const int k = k0 + __builtin_ctzll(mask);
         mask &= mask - 1ull;
         if (!occ) occ = sphere_any<(MODE >= 1)>(lds, k, o, R, a, a_sane);
+        if (!RT_SHADOW_EXIT_CHECKS && mask && __builtin_amdgcn_ballot_w64(!occ) == 0ull) break;   // (only if spheres remain)
       }
       RT_MARK(8);
     }
     const double *pl = lds.recs() + (MODE >= 1 ? 0 : opaque(p.S) * SPH_STRIDE);
     for (int k = 0; k < P; ++k) {
-        if (__builtin_amdgcn_ballot_w64(!occ) == 0ull) break;
+        if (RT_SHADOW_EXIT_CHECKS && __builtin_amdgcn_ballot_w64(!occ) == 0ull) break;   // (an empty exec mask skips the test below anyway)
         if (!occ) {
             const double *g = pl + k * PL_STRIDE;
             double den, num;
