@@ -527,6 +527,8 @@ int dispatch(rt_ctx *ctx, const rt_params *p, rt::KParams &k, bool lattice, hipS
         k.cost = (unsigned *)f.cost.p;
     }
     k.nframes = nframes; k.bpf = (int)grid; k.frame_stride = frame_stride; k.order_tiles = otiles ? 1 : 0;
+    rt::div_magic((unsigned)k.bpf, k.bpf_magic, k.bpf_shift);
+    rt::div_magic((unsigned)k.tiles_y, k.tiles_y_magic, k.tiles_y_shift);
     k.seq_offset = (ctx->seq_order < 0 ? wpw == 2 : ctx->seq_order != 0) ? (int)items : 0;
     void *args[] = {(void *)&k};
     RT_HIP(ctx, hipLaunchKernel(fn, dim3(grid * (unsigned)nframes), dim3(wgt), args, lds, stream));

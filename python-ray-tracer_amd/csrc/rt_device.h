@@ -118,6 +118,7 @@ struct KParams {
                                // axis-aligned unit normal.  A kernel argument lives in an SGPR, so the plane tests of
                                // the usual scenes (a floor, a wall) branch on the scalar unit without touching the VALU
     int aa, u8_rgb, tiles_y, ntiles;
+    unsigned tiles_y_magic, tiles_y_shift, bpf_magic, bpf_shift;   // div_magic() of tiles_y and bpf (the host fills them)
     int anchors, spp;          // L+1 if the anchored cull table is in use, else 0; samples per pixel (stochastic AA)
     unsigned seed;             // jitter hash seed (stochastic AA)
     int u8_hwc;                // uint8 frame interleaved as [y][x][3] (an image), row pitch = plane_stride pixels
@@ -130,6 +131,25 @@ struct KParams {
     double amb, lamb;
     double refl_pow[16];
 };
+
+// Division of n < 2^31 by a launch constant d without the backend's 20-instruction sequence (v_rcp_iflag_f32 and two
+// correction steps, on the VECTOR unit even for wave-uniform operands): q = mulhi(n, M) >> sh with M = floor(2^(31+l) / d) + 1,
+// l = ceil(log2 d), sh = l - 1 — exact because n d < 2^(31+l) (Granlund-Montgomery); d = 1 passes n through.  Every wave
+// divides its tile index by the tiles per column, and in multi-frame launches its block index by the blocks per frame,
+// twice: 31 of the headline kernel's vector instructions (and as many scalar ones) per wave, C2 -1.5 %, C4 -1.7 %.
+// tests/test_host_helpers.py checks the formula exhaustively on small ranges and on random operands.
+__host__ __device__ inline void div_magic(unsigned d, unsigned &M, unsigned &sh)
+{
+    if (d <= 1u) { M = 0u; sh = 0u; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    M = (unsigned)((1ull << (31 + l)) / d + 1ull);
+    sh = l - 1u;
+}
+__device__ __forceinline__ int div_by(int n, int d, unsigned M, unsigned sh)
+{
+    return d == 1 ? n : (int)(__umulhi((unsigned)n, M) >> sh);
+}
 
 struct V3 { double x, y, z; };
 struct F3 { float x, y, z; };
@@ -1527,7 +1547,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     int bid = (int)blockIdx.x;
     const unsigned *ord = p.order;
     if (p.nframes > 1) {
-        const int frame = bid / p.bpf;
+        const int frame = div_by(bid, p.bpf, p.bpf_magic, p.bpf_shift);
         bid -= frame * p.bpf;
         if (ord && frame < p.nframes - 1) ord += p.seq_offset;
     }
@@ -1547,7 +1567,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     const int tile = WPW >= RT_TILE_ORDER_MIN_WPW ? __builtin_amdgcn_readfirstlane(tile_v) : tile_v;
     if (tile >= p.ntiles) return;                                             // whole wave, after the barriers
     const unsigned long long t_begin = (p.tile_cycles || p.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int tx = tile / p.tiles_y, ty = tile - tx * p.tiles_y;
+    const int tx = div_by(tile, p.tiles_y, p.tiles_y_magic, p.tiles_y_shift), ty = tile - tx * p.tiles_y;
     const int x = p.x0 + tx * TILE + (lane >> 3);
     const int y = ty * TILE + (lane & 7);
     bool inb = (x < p.x1) && (y < p.h);
@@ -1618,7 +1638,7 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
             q[0] = R; q[1] = G; q[2] = B;
         } else {
             // the frame index is formed again here (a wave-uniform division) instead of being carried through the trace
-            const long long fo = opaque(p.nframes) > 1 ? (long long)((int)blockIdx.x / p.bpf) * p.frame_stride : 0ll;
+            const long long fo = opaque(p.nframes) > 1 ? (long long)div_by((int)blockIdx.x, p.bpf, p.bpf_magic, p.bpf_shift) * p.frame_stride : 0ll;
             store_pixel(p, off, fo, R, G, B);
         }
     }

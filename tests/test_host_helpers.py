@@ -79,3 +79,33 @@ def test_true_aspect_option():
     assert ref[1] == 1.0 and abs(tru[1] - 16 / 9) < 1e-15 and tru[2] == (-2 * tru[1]) / 1919.0 and ref[3:] == tru[3:]
     g = Camera((32, 18), [-2, 0, 2.0], [0, -30, 0], true_aspect=True).generate_pixel_locations()
     assert g[1, 0, 0] == 32 / 18 and g[1, -1, 0] == -g[1, 0, 0] and g.raygen is not None
+
+
+def test_division_by_launch_constants():
+    """rt_device.h div_magic / div_by (tile index / tiles per column, block index / blocks per frame): q = mulhi(n, M) >> sh with
+    M = floor(2^(31+l) / d) + 1, l = ceil(log2 d), sh = l - 1, must equal n // d for every n < 2^31 — restated here and checked
+    exhaustively for small operands, at the edges, and on random ones (the GPU suite then runs the device code on odd frame sizes)."""
+    import random
+
+    def magic(d):
+        if d <= 1:
+            return 0, 0
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return (1 << (31 + l)) // d + 1, l - 1
+
+    def div_by(n, d, M, sh):
+        return n if d == 1 else ((n * M) >> 32) >> sh
+
+    for d in range(1, 1200):
+        M, sh = magic(d)
+        assert M < 2 ** 32
+        for n in list(range(0, 2500)) + [2 ** 31 - 1, 2 ** 31 - 2, 2 ** 30, d * 1000 - 1, d * 1000]:
+            assert div_by(n, d, M, sh) == n // d, (n, d)
+    rng = random.Random(7)
+    for _ in range(300000):
+        d = max(1, rng.randint(1, 2 ** rng.randint(1, 31) - 1))
+        n = rng.randint(0, 2 ** 31 - 1)
+        M, sh = magic(d)
+        assert M < 2 ** 32 and div_by(n, d, M, sh) == n // d, (n, d)
