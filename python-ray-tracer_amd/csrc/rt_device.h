@@ -46,6 +46,9 @@
 #ifndef RT_FAST_DIVSQRT
 #define RT_FAST_DIVSQRT 1
 #endif
+#ifndef RT_CULL_PAIRS_WPW2
+#define RT_CULL_PAIRS_WPW2 1   // the two-wave kernels too: 16 spheres -3 %, the headline -0.6 %
+#endif
 #ifndef RT_SHADOW_EXIT_CHECKS
 #define RT_SHADOW_EXIT_CHECKS 0
 #endif
@@ -363,6 +366,7 @@ struct Lds {
     const float *col32;    // (Sp + planes) x {R,G,B,-}: colours (MODE 1 kernels only; nullptr otherwise)
     int NC;
     int wave;              // this wave's index in its workgroup (scalar)
+    bool pairs;            // a compile-time constant per kernel: the wave-uniform cull keeps two table entries in flight (cull4)
     bool groups;           // a compile-time constant per kernel: test a chunk's group of clusters before its clusters (MODE 2 kernels)
 #ifdef RT_REGION_STATS
     unsigned *reg;         // measurement build: 32 words per wave — cycles per code region [0, 24), bounce class [30], last stamp [31]
@@ -566,14 +570,30 @@ __device__ __forceinline__ bool box_open(const f4 lo, const f4 hi, const RayBox 
 // The tables are padded with entries that always certify a miss (tau = +inf, r2 = -inf), so groups of 4 need no
 // bounds handling and use immediate LDS offsets.
 // Returns 16 acc + bits (entries are visited from the highest to the lowest).
-template <bool ANCH, bool SELF>
+// PAIRS: two entries are read before either is tested — one LDS round trip per two tests instead of one per test, for four more
+// live VGPRs.  The wave-uniform kernels take it (config 4 -2.7 %, 36 ... 144 spheres -3 ... -5 %, 16 spheres -3 %, the headline -0.6 %,
+// the 9-tap kernels -0.7 ... -2.6 %); the lane-owned kernels, which run
+// this cull for their primary rays at 128 VGPRs with spills, lose 0.8 % with it and keep one entry in flight.
+template <bool ANCH, bool SELF, bool PAIRS>
 __device__ __forceinline__ unsigned cull4(lds_cf4 *base, const RayF &q, int jsel, unsigned acc)
 {
     static_assert(CULL_STRIDE == 4, "one 16-byte entry per (anchor, sphere)");
+    f4 pending = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int u = 3; u >= 0; --u) {
-        asm volatile("" ::: "memory");                        // one entry in flight (registers decide occupancy)
-        const f4 e = base[u];
+        f4 e;
+        if constexpr (PAIRS) {
+            if (u & 1) {
+                asm volatile("" ::: "memory");
+                e = base[u];
+                f4 enext = base[u - 1];
+                asm volatile("" : "+v"(e), "+v"(enext));      // both loaded before either is used
+                pending = enext;
+            } else e = pending;
+        } else {
+            asm volatile("" ::: "memory");                    // one entry in flight (registers decide occupancy)
+            e = base[u];
+        }
         lanemask open;                                        // live lanes without a certificate for this entry
         if constexpr (ANCH) {
             const float sd = __builtin_fmaf(e[2], q.R.z, __builtin_fmaf(e[1], q.R.y, e[0] * q.R.x));
@@ -619,18 +639,18 @@ __device__ __forceinline__ unsigned long long cull_mask_t(const Lds &lds, int S,
         // +9..+20 %)
         lds_cf4 *cbase = pin_lds(ANCH ? lds.ctab + ((size_t)anchor * NCp + c0) * CULL_STRIDE : lds.csph32 + 4 * c0);
         unsigned cm = 0;
-        for (int j = 0; j < nc; j += 4) cm |= cull4<ANCH, false>(cbase + j, q, -1, 0u) << j;
+        for (int j = 0; j < nc; j += 4) cm |= (lds.pairs ? cull4<ANCH, false, true>(cbase + j, q, -1, 0u) : cull4<ANCH, false, false>(cbase + j, q, -1, 0u)) << j;
         while (cm) {                                                          // clusters some lane might hit
             const int c = __builtin_ctz(cm);
             cm &= cm - 1u;
             const int jb = c * CLUSTER;
-            const unsigned hi = cull4<ANCH, SELF>(sbase + jb + 4, q, selfj - jb - 4, 0u);
-            const unsigned lohi = cull4<ANCH, SELF>(sbase + jb, q, selfj - jb, hi);
+            const unsigned hi = lds.pairs ? cull4<ANCH, SELF, true>(sbase + jb + 4, q, selfj - jb - 4, 0u) : cull4<ANCH, SELF, false>(sbase + jb + 4, q, selfj - jb - 4, 0u);
+            const unsigned lohi = lds.pairs ? cull4<ANCH, SELF, true>(sbase + jb, q, selfj - jb, hi) : cull4<ANCH, SELF, false>(sbase + jb, q, selfj - jb, hi);
             mask |= (unsigned long long)lohi << jb;
         }
     } else {
         const int npad = pad4(n);
-        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)cull4<ANCH, SELF>(sbase + j, q, selfj - j, 0u) << j;
+        for (int j = 0; j < npad; j += 4) mask |= (unsigned long long)(lds.pairs ? cull4<ANCH, SELF, true>(sbase + j, q, selfj - j, 0u) : cull4<ANCH, SELF, false>(sbase + j, q, selfj - j, 0u)) << j;
     }
     return mask;
 }
@@ -1528,11 +1548,11 @@ __global__ __launch_bounds__(64 * WPW, MODE >= 2 ? RT_W_LANES : (AA ? (PARK ? RT
     // NC a constant 0 there, none of the cluster code is compiled into those kernels (the headline kernel sits in a narrow
     // register optimum)
 #ifdef RT_REGION_STATS
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), MODE >= 2, wgstat + 4, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), MODE < 2 && (WPW >= 4 || RT_CULL_PAIRS_WPW2), MODE >= 2, wgstat + 4, accum};
     for (int i = threadIdx.x & 63; i < 32; i += 64) lds.reg[(threadIdx.x >> 6) * 32 + i] = 0u;
     if ((threadIdx.x & 63) == 0) lds.reg[(threadIdx.x >> 6) * 32 + 31] = (unsigned)__builtin_amdgcn_s_memtime();
 #else
-    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), MODE >= 2, accum};
+    const Lds lds{sph32, tab, csph32, ctab, cbox, sph32 + tl.gbox, sph32 + tl.gtab, MODE == 1 ? sph32 + tl.col32 : nullptr, WPW == 2 ? 0 : p.NC, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), MODE < 2 && (WPW >= 4 || RT_CULL_PAIRS_WPW2), MODE >= 2, accum};
 #endif
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
